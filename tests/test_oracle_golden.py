@@ -1,0 +1,183 @@
+"""Pins the CPU oracle against every golden vector the reference's own tests hold for the hot
+path and against the reference-built index files.  CPU only."""
+import hashlib
+import json
+import os
+import struct
+
+import pytest
+
+import oracle
+import refindex
+from conftest import CARS_DESC, WORDS_DESC, GOLDEN
+
+MERGERS = ["scan_count", "cp_merge", "merge_skip", "divide_skip"]
+
+
+def desc_kwargs(d):
+    return dict(ngram_size=d["nGramSize"], wrap=tuple(d["wrap"]), pad=d["pad"], alphabet=tuple(d["alphabet"]))
+
+
+@pytest.mark.parametrize("algo", MERGERS)
+def test_merge_tables(reference_tests, algo):
+    # pkg/merger/list_merger_test.go:42-175
+    for case in reference_tests["merge"]["cases"]:
+        got = {}
+        for pos, ov in oracle.merge(algo, case["rid"], case["t"]):
+            got.setdefault(str(ov), []).append(pos)
+        assert got == case["expected"], (algo, case)
+
+
+def test_overlap_overflow_panics(reference_tests):
+    # pkg/merger/list_merger_test.go:11-17
+    assert oracle.lib().or_candidate_increment(reference_tests["overlap_overflow"]["overlap"]) == -2
+    assert oracle.lib().or_candidate_increment(7) == 8
+
+
+def test_intersect(reference_tests):
+    for case in reference_tests["intersect"]["cases"]:
+        got = [p for p, _ in oracle.merge("intersector", case["rid"], 0)]
+        assert got == case["expected"]
+        # overlap reported by the intersector is the number of lists (list_intersector.go:57)
+        assert all(o == len(case["rid"]) for _, o in oracle.merge("intersector", case["rid"], 0))
+
+
+def test_ngram_tokenizer(reference_tests):
+    for case in reference_tests["ngram_tokenizer"]["cases"]:
+        got = [t.decode("utf-8") for t in oracle.ngram_tokenize(case["word"], case["k"])]
+        assert got == case["ngrams"], case
+
+
+def test_ngram_tokenizer_edge_semantics():
+    # ngram_tokenizer.go:18 byte-length guard; >= q bytes but <= q runes gives the whole text once
+    assert oracle.ngram_tokenize("ab", 3) == []
+    assert oracle.ngram_tokenize("жи", 3) == ["жи".encode()]        # 4 bytes, 2 runes
+    assert oracle.ngram_tokenize("abc", 3) == [b"abc"]
+    assert oracle.ngram_tokenize("abcdefghkl123456йцукен", 3)[-1] == "кен".encode()
+
+
+def test_alphabet(reference_tests):
+    a = reference_tests["alphabet"]
+    for ch, exp in a["russian"]:
+        assert oracle.alphabet_has(["russian"], ch) == exp, ch
+    for ch, exp in a["composite_russian_english_numbers"]:
+        assert oracle.alphabet_has(["russian", "english", "numbers"], ch) == exp, ch
+    assert oracle.alphabet_has(["$^"], "^") and oracle.alphabet_has(["$^"], "$") and not oracle.alphabet_has(["$^"], "a")
+
+
+def test_to_lower_go_semantics():
+    assert oracle.to_lower("NISSAN March") == b"nissan march"
+    assert oracle.to_lower("ЖИГУЛИ Ё") == "жигули ё".encode()
+    assert oracle.to_lower("İ") == b"i"                       # unicode.ToLower(U+0130) == 'i' (simple mapping)
+    assert oracle.to_lower(b"A\xffB\xc3") == b"A\xffB\xc3".replace(b"\xff", "�".encode()).replace(
+        b"\xc3", "�".encode()).lower()                  # strings.Map re-encodes invalid bytes as U+FFFD
+
+
+def test_topk(reference_tests):
+    t = reference_tests["topk"]
+    got, lowest, can = oracle.topk(t["k"], t["inserts"], probe=t["can_take"][0])
+    assert got == [tuple(x) for x in t["expected"]]
+    assert lowest == t["lowest"] and can == t["can_take"][1]
+
+
+def test_topk_tie_break_prefers_smaller_doc_id():
+    # Candidate.Less collector.go:20-26: equal score -> larger key is "less" (worse)
+    got, _, _ = oracle.topk(2, [(9, 0.5), (3, 0.5), (7, 0.5), (1, 0.25)])
+    assert got == [(3, 0.5), (7, 0.5)]
+
+
+def test_suggest_auto(reference_tests):
+    t = reference_tests["suggest_auto"]
+    ix = oracle.OracleIndex(reference_tests["small_collection"], **desc_kwargs(t["description"]))
+    for algo in ["cp_merge", "scan_count", "merge_skip", "divide_skip"]:
+        got = ix.suggest(t["query"], t["metric"], t["similarity"], t["topK"], algo=algo)
+        assert [d for d, _ in got] == t["expected_ids"]
+
+
+def test_autocomplete(reference_tests):
+    t = reference_tests["autocomplete"]
+    ix = oracle.OracleIndex(reference_tests["small_collection"], **desc_kwargs(t["description"]))
+    assert ix.autocomplete(t["query"], t["limit"]) == t["expected_ids"]
+
+
+def test_example(reference_tests):
+    t = reference_tests["example"]
+    coll = reference_tests["small_collection"]
+    ix = oracle.OracleIndex(coll, **desc_kwargs(t["description"]))
+    got = ix.suggest(t["query"], t["metric"], t["similarity"], t["topK"])
+    assert [coll[d] for d, _ in got] == t["expected_values"]
+
+
+@pytest.fixture(scope="module")
+def cars_index(cars_lines):
+    return oracle.OracleIndex(cars_lines, **CARS_DESC)
+
+
+def test_service_cars(reference_tests, cars_lines, cars_index):
+    t = reference_tests["service_cars"]
+    for q, exp in zip(t["queries"], t["expected_values"]):
+        for tighten in (False, True):
+            got = cars_index.suggest(q, t["metric"], t["similarity"], t["topK"], tighten=tighten)
+            assert [cars_lines[d].decode() for d, _ in got] == exp, (q, tighten)
+
+
+def test_cars_index_matches_reference_files(cars_index, golden_dir):
+    """Every (segment, term) list of the oracle-built cars index equals the list the reference
+    wrote to db/cars.{hd,dl}: same keys, same raw lengths, same postings incl. duplicates."""
+    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "cars.hd"), os.path.join(golden_dir, "cars.dl"))
+    mine = cars_index.lists()
+    assert cars_index.n_segments == n_idx == 52
+    assert set(mine) == set(ref) and len(ref) == 36285
+    bad = [k for k in ref if mine[k] != (ref[k][0], ref[k][1])]
+    assert not bad, bad[:5]
+    assert mine[(12, b"an$")][1] == [1080, 1082, 1111, 2244, 2245, 3235, 3235, 3238, 3239, 3240, 3240, 3247, 3250,
+                                     3251, 3252, 3253, 3254, 3259, 3265]
+
+
+def test_words_index_matches_reference_digest(words_lines, golden_dir):
+    """235 887-word index vs the digest of db/words.{hd,dl} (tools/make_golden.py): per-segment sha256
+    over every list (VB, skip-VB and roaring classes), plus explicit samples."""
+    with open(os.path.join(golden_dir, "words_index_digest.json")) as f:
+        dig = json.load(f)
+    ix = oracle.OracleIndex(words_lines, **WORDS_DESC)
+    mine = ix.lists()
+    assert ix.n_segments == dig["n_indices"] and len(mine) == dig["n_lists"]
+    assert sum(v[0] for v in mine.values()) == dig["n_postings_raw"]
+    per = {}
+    for (seg, term) in sorted(mine):
+        raw_len, post = mine[(seg, term)]
+        h = per.setdefault(seg, [0, 0, hashlib.sha256()])
+        h[0] += 1
+        h[1] += len(post)
+        h[2].update(struct.pack("<II", seg, len(term)) + term + struct.pack("<II", raw_len, len(post)))
+        h[2].update(struct.pack("<%dI" % len(post), *post))
+    got = {str(s): [v[0], v[1], v[2].hexdigest()] for s, v in per.items()}
+    assert got == dig["segments"]
+    for seg, term_hex, raw_len, post in dig["samples"]:
+        assert mine[(seg, bytes.fromhex(term_hex))] == (raw_len, post)
+
+
+def test_probe_predictions_cross_check(cars_index):
+    # line-by-line emulation predictions (unverified against Go) — a cross-check of two
+    # independent restatements, not a pin.
+    got = cars_index.suggest("Nissan Mar", "jaccard", 0.5, 5)
+    assert got == [(3265, 0.6923076923076923), (3230, 0.5333333333333333)]
+    got = cars_index.suggest("Nissan Mar", "cosine", 0.5, 5)
+    assert [d for d, _ in got] == [3265, 3230, 3254, 3231, 3256]
+
+
+def test_all_mergers_agree_on_cars(reference_tests, cars_index):
+    for q in reference_tests["workloads"]["cars_cosine_0.5_k5"] + reference_tests["service_cars"]["queries"]:
+        base = cars_index.suggest(q, "cosine", 0.5, 5, algo="cp_merge")
+        for algo in ("scan_count", "merge_skip", "divide_skip"):
+            assert cars_index.suggest(q, "cosine", 0.5, 5, algo=algo) == base, (q, algo)
+
+
+def test_reference_crash_inputs_are_flagged(cars_index):
+    # query far longer than any entry: bMin > nSegments-1 -> the reference panics (negative channel cap)
+    import random
+    rng = random.Random(7)
+    long_q = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(400))
+    assert cars_index.suggest(long_q, "jaccard", 0.5, 5) == oracle.STATUS_REFERENCE_PANICS
+    # empty token list -> empty result, no error (suggester.go:49-51)
+    assert cars_index.suggest("", "jaccard", 0.5, 5) == []
