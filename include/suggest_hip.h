@@ -1,0 +1,129 @@
+/* suggest_hip.h — C ABI of libsuggest_hip.so, the MI355X (gfx950) engine behind suggest-go's
+ * n-gram fuzzy-search path.
+ *
+ * The reference has no FFI; its extension seam is the pair of Go interfaces
+ *   suggest.Builder{Build() (NGramIndex, error)}          pkg/suggest/ngram_index_builder.go:14-17
+ *   suggest.NGramIndex = Suggester + Autocomplete          pkg/suggest/ngram_index.go:7-10
+ * consumed by Service.AddIndex / Suggest / Autocomplete    pkg/suggest/service.go:78-173.
+ * A cgo shim implementing those two interfaces binds exactly the entry points below
+ * (see INTEGRATION.md for the shim).  Every function cites the reference code it replaces.
+ *
+ * Conventions: return 0 on success, a negative SG_E_* code on failure (sg_last_error() gives a
+ * thread-local message); the caller owns every host buffer; the library owns device memory;
+ * no callbacks; every entry point may be called concurrently from any thread on the same handle
+ * (the handle is immutable after sg_index_upload and reference counted).
+ */
+#ifndef SUGGEST_HIP_H
+#define SUGGEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sg_index sg_index;
+
+/* IndexDescription — pkg/suggest/config.go:25-35 (the fields the tokenizer and index use) */
+typedef struct sg_desc {
+  uint32_t ngram_size;          /* NGramSize, 1..8 (pkg/analysis/ngram_tokenizer.go:3) */
+  const char* wrap_start;       /* Wrap[0], UTF-8, NUL terminated */
+  const char* wrap_end;         /* Wrap[1] */
+  const char* pad;              /* Pad */
+  const char* const* alphabet;  /* Alphabet: "english" | "russian" | "numbers" | literal rune set
+                                   (pkg/alphabet/alphabet.go:23-36) */
+  uint32_t n_alphabet;
+} sg_desc;
+
+/* metric.Metric implementations — pkg/metric/{jaccard,cosine,dice,exact,overlap}.go */
+enum sg_metric { SG_JACCARD = 0, SG_COSINE = 1, SG_DICE = 2, SG_EXACT = 3, SG_OVERLAP = 4 };
+
+enum sg_error {
+  SG_OK = 0,
+  SG_E_INVALID = -1,      /* bad argument (k == 0, similarity outside (0,1], q outside 1..8 ...) —
+                             the checks of NewSearchConfig, pkg/suggest/search.go:18-35 */
+  SG_E_UNSUPPORTED = -2,  /* description outside what the packed 64-bit term key can hold */
+  SG_E_NOT_UPLOADED = -3,
+  SG_E_HIP = -4,          /* HIP runtime error; message has the hipError string */
+  SG_E_NOMEM = -5
+};
+
+/* Values stored in out_counts[i] instead of a count, for queries the reference itself does not
+ * answer (pkg/suggest/suggester.go:62: the clipped window [bMin,bMax] is empty) and for queries
+ * beyond the device path's limits.  Rows of such queries are left zeroed. */
+#define SG_COUNT_REF_PANIC 0xFFFFFFFFu     /* reference: make(chan, negative) panics */
+#define SG_COUNT_REF_DEADLOCK 0xFFFFFFFEu  /* reference: capacity-0 channel, send blocks forever */
+#define SG_COUNT_TOO_LONG 0xFFFFFFFDu      /* more than SG_MAX_QUERY_TERMS n-grams */
+#define SG_MAX_QUERY_TERMS 128u
+#define SG_MAX_TOPK 1024u
+
+/* suggest.Index + Writer.AddDocument/Commit + Reader.Read
+ * (pkg/suggest/indexer.go:14-45, pkg/index/indexer_writer.go:66-145, index_reader.go:29-120):
+ * tokenises docs[i] = utf8[offs[i]..offs[i+1]) (docID = i, dictionary order) and builds the
+ * cardinality-segmented inverted index as term-major CSR in host memory. */
+int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out);
+
+/* Copies the CSR index into the HBM of `device` (one replica per GPU; per-process). */
+int sg_index_upload(sg_index* index, int device);
+
+/* nGramSuggester.Suggest for a batch of queries — pkg/suggest/suggester.go:46-131 with
+ * newFuzzyCollectorManager(k) (collector.go:143-149): tokenise, window [MinY,MaxY], per segment
+ * T-occurrence merge (pkg/index/searcher.go:28-78, pkg/merger/cp_merge.go:19-120 result set),
+ * score 1-Distance (scorer.go:29-31), top-k by (score desc, docID asc) (collector.go:20-26,
+ * topk.go:82-147).  Row i of out_ids/out_scores (k entries each) holds the candidates of query i
+ * best first; out_counts[i] = how many (or an SG_COUNT_* flag).  Host buffers; synchronous. */
+int sg_suggest_batch(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
+                     double similarity, uint32_t k, uint32_t* out_ids, double* out_scores, uint32_t* out_counts);
+
+/* Same, on buffers already resident in the HBM of the index's device; enqueued on `stream`
+ * (a hipStream_t, NULL = the legacy default stream) and asynchronous w.r.t. the host. */
+int sg_suggest_batch_device(sg_index* index, const void* d_q_utf8, const void* d_q_offs, uint32_t n_q, int metric,
+                            double similarity, uint32_t k, void* d_out_ids, void* d_out_scores, void* d_out_counts,
+                            void* stream);
+
+/* nGramAutocomplete.Autocomplete with newFirstKCollectorManager(limit) —
+ * pkg/suggest/autocomplete.go:40-77, collector.go:48-115: the `limit` smallest docIDs whose
+ * n-gram set contains every n-gram of the (tail-unwrapped) query. */
+int sg_autocomplete_batch(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                          uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
+int sg_autocomplete_batch_device(sg_index* index, const void* d_q_utf8, const void* d_q_offs, uint32_t n_q,
+                                 uint32_t limit, void* d_out_ids, void* d_out_counts, void* stream);
+
+/* Reference counting: the Go shim retains while a query is in flight and releases from a
+ * finalizer, mirroring the reference's mmap release (pkg/index/index_reader.go:49-51). */
+void sg_index_retain(sg_index* index);
+void sg_index_release(sg_index* index);
+
+const char* sg_last_error(void);
+
+/* ---- introspection (tests, bench.py) ---------------------------------------------------- */
+typedef struct sg_stats {
+  uint64_t n_docs, n_segments, n_terms, n_lists, n_postings /* (term,doc) pairs stored */,
+      n_postings_raw /* incl. repeated terms of a doc, as the reference stores them */, posting_bytes /* padded */,
+      table_bytes, device_bytes;
+} sg_stats;
+int sg_index_stats(const sg_index* index, sg_stats* out);
+
+/* Tokens of `text` as the index sees them, one packed 64-bit term key each (DESIGN.md §Term keys);
+ * returns the token count (may exceed cap; only cap are written).  NewSuggestTokenizer /
+ * NewAutocompleteTokenizer, pkg/suggest/tokenizer.go:9-34. */
+int sg_tokenize(const sg_index* index, const uint8_t* text, uint32_t len, int autocomplete, uint64_t* out_keys,
+                uint32_t cap);
+/* Renders a term key back to the reference's term string (UTF-8); returns its byte length. */
+int sg_term_string(const sg_index* index, uint64_t key, char* out, uint32_t cap);
+/* Posting list of (segment, term key) from the host CSR: returns the stored (de-duplicated)
+ * length, writes up to cap docIDs; *raw_len = length incl. a doc's repeated terms. -1 if absent. */
+int64_t sg_index_list(const sg_index* index, uint32_t segment, uint64_t key, uint32_t* out, uint64_t cap,
+                      uint64_t* raw_len);
+/* Enumerates the non-empty (segment, term) lists: fills up to cap entries, returns the total. */
+uint64_t sg_index_lists(const sg_index* index, uint32_t* out_segments, uint64_t* out_keys, uint64_t cap);
+
+/* Algorithmic bytes of a suggest batch: per query 4*sum of |postings| over every
+ * admissible segment and present term + len(query) + 12*k.  Host-side accounting for bench.py. */
+int sg_suggest_algorithmic_bytes(const sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                                 int metric, double similarity, uint32_t k, uint64_t* out_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUGGEST_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libsuggest_hip.so (include/suggest_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load this module raises.
+Import torch *before* this module when torch is used in the same process, so that both resolve
+the same libamdhip64 (SONAME libamdhip64.so.7).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsuggest_hip.so")
+
+SG_COUNT_REF_PANIC = 0xFFFFFFFF
+SG_COUNT_REF_DEADLOCK = 0xFFFFFFFE
+SG_COUNT_TOO_LONG = 0xFFFFFFFD
+SG_MAX_QUERY_TERMS = 128
+SG_MAX_TOPK = 1024
+
+EXPORTS = [
+    "sg_index_build", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
+    "sg_autocomplete_batch_device", "sg_index_retain", "sg_index_release", "sg_last_error", "sg_index_stats",
+    "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
+]
+
+
+class SgDesc(C.Structure):
+    _fields_ = [("ngram_size", C.c_uint32), ("wrap_start", C.c_char_p), ("wrap_end", C.c_char_p), ("pad", C.c_char_p),
+                ("alphabet", C.POINTER(C.c_char_p)), ("n_alphabet", C.c_uint32)]
+
+
+class SgStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_docs", "n_segments", "n_terms", "n_lists", "n_postings", "n_postings_raw",
+                                          "posting_bytes", "table_bytes", "device_bytes")]
+
+
+class SuggestHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsuggest_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C suggest_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    L.sg_index_build.argtypes = [vp, vp, u32, C.POINTER(SgDesc), C.POINTER(vp)]
+    L.sg_index_upload.argtypes = [vp, i32]
+    L.sg_suggest_batch.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
+    L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
+    L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+    L.sg_index_retain.argtypes = [vp]
+    L.sg_index_retain.restype = None
+    L.sg_index_release.argtypes = [vp]
+    L.sg_index_release.restype = None
+    L.sg_last_error.restype = C.c_char_p
+    L.sg_index_stats.argtypes = [vp, C.POINTER(SgStats)]
+    L.sg_tokenize.argtypes = [vp, C.c_char_p, u32, i32, vp, u32]
+    L.sg_term_string.argtypes = [vp, u64, C.c_char_p, u32]
+    L.sg_index_list.argtypes = [vp, u32, u64, vp, u64, C.POINTER(u64)]
+    L.sg_index_list.restype = C.c_int64
+    L.sg_index_lists.argtypes = [vp, vp, vp, u64]
+    L.sg_index_lists.restype = u64
+    L.sg_suggest_algorithmic_bytes.argtypes = [vp, vp, vp, u32, i32, dbl, u32, C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise SuggestHipError(rc, lib().sg_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,877 @@
+// engine.hip — MI355X (gfx950 / CDNA4) engine of libsuggest_hip: device index replica, the fused
+// per-query search kernel and the C ABI of include/suggest_hip.h.
+//
+// One 64-lane wavefront (= one workgroup) owns one query end to end:
+//   tokenise (pkg/suggest/tokenizer.go:9-34)  ->  window [MinY,MaxY] (pkg/metric/*.go)
+//   -> for every admissible cardinality segment B: stream the query terms' posting lists once
+//      with 16-byte coalesced loads, count candidates in LDS (lossy u16 counters + exact
+//      verification), keep docs with overlap >= T(B)
+//      (the result set of searcher.Search + cpMerge.Merge, pkg/index/searcher.go:28-78,
+//      pkg/merger/cp_merge.go:19-120)
+//   -> score 1-Distance in IEEE double (pkg/suggest/scorer.go:29-31)
+//   -> wave-level top-k by (score desc, docID asc) (pkg/suggest/collector.go:20-26, topk.go:82-147).
+// Integer/index work: no MFMA; the bound is HBM bandwidth on the posting stream.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "sg_internal.h"
+
+namespace sg {
+
+#define SG_MAX_A 128           // == SG_MAX_QUERY_TERMS
+#define SG_MAX_RUNES 144       // SG_MAX_A + 2*8 wrap runes
+#define SG_CAND_CAP 64
+#define SG_K_LDS 64
+#define SG_WRAP_MAX 8
+
+struct DeviceIndex {
+  const uint32_t* postings;
+  const uint32_t* seg_off;
+  const TermSlot* slots;
+  const uint8_t* ascii_sym;    // [128]
+  const uint8_t* ascii_alpha;  // [128]
+  const uint32_t* na_rune;
+  const uint8_t* na_sym;
+  const uint8_t* na_alpha;
+  const uint32_t* lower_from;
+  const uint32_t* lower_to;
+  uint32_t slot_mask, n_na, n_lower;
+  uint32_t S, n_terms, q;
+  uint32_t wrap0[SG_WRAP_MAX], wrap1[SG_WRAP_MAX];
+  uint32_t n_wrap0, n_wrap1, n_pad;
+  uint8_t pad_sym[8];
+};
+
+struct BatchArgs {
+  DeviceIndex ix;
+  const uint8_t* q_blob;
+  const uint64_t* q_offs;
+  uint32_t* out_ids;
+  double* out_scores;   // null in autocomplete mode
+  uint32_t* out_counts;
+  uint64_t* scratch_s;  // [n_q*k] top-k working rows when k > SG_K_LDS
+  uint32_t* scratch_id;
+  double alpha;
+  uint32_t n_q, k;
+  int metric, autocomplete;
+  uint32_t log2_nb;     // u16 buckets per wave = 1 << log2_nb
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+__device__ __forceinline__ uint32_t readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// pkg/metric — IEEE binary64, Go's evaluation order; built with -ffp-contract=off
+__device__ double d_floor_div_clamp(double x, double hi) { double f = floor(x); return f > hi ? hi : f; }
+__device__ int d_min_y(int m, double alpha, int size) {
+  switch (m) {
+    case SG_JACCARD: return (int)ceil(alpha * (double)size);
+    case SG_COSINE: return (int)ceil(alpha * alpha * (double)size);
+    case SG_DICE: return (int)ceil(alpha / (2 - alpha) * (double)size);
+    case SG_EXACT: return size;
+    default: return 1;
+  }
+}
+__device__ int d_max_y(int m, double alpha, int size, int cap) {  // result clamped to cap (>= any usable bMax)
+  double v;
+  switch (m) {
+    case SG_JACCARD: v = floor((double)size / alpha); break;
+    case SG_COSINE: v = floor((double)size / (alpha * alpha)); break;
+    case SG_DICE: v = floor((2 - alpha) / alpha * (double)size); break;
+    case SG_EXACT: v = (double)size; break;
+    default: v = 32767.0; break;
+  }
+  return v > (double)cap ? cap : (int)v;
+}
+__device__ int d_threshold(int m, double alpha, int a, int b) {
+  switch (m) {
+    case SG_JACCARD: return (int)ceil(alpha * (double)(a + b) / (1 + alpha));
+    case SG_COSINE: return (int)ceil(alpha * sqrt((double)(a * b)));
+    case SG_DICE: return (int)ceil(0.5 * alpha * (double)(a + b));
+    case SG_EXACT: return a;
+    default: return (int)ceil(alpha * fmin((double)a, (double)b));
+  }
+}
+__device__ double d_score(int m, int inter, int a, int b) {  // 1 - Distance(...), two roundings
+  double dist;
+  switch (m) {
+    case SG_JACCARD: dist = 1 - (double)inter / (double)(a + b - inter); break;
+    case SG_COSINE: dist = 1 - (double)inter / sqrt((double)(a * b)); break;
+    case SG_DICE: dist = 1 - (double)(2 * inter) / (double)(a + b); break;
+    case SG_EXACT: dist = 0; break;
+    default: dist = 1 - (double)inter / fmin((double)a, (double)b); break;
+  }
+  return 1 - dist;
+}
+// order-preserving map double -> u64 (bigger = better score)
+__device__ __forceinline__ uint64_t score_bits(double x) {
+  uint64_t b = (uint64_t)__double_as_longlong(x);
+  return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double bits_score(uint64_t k) {
+  uint64_t b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ bool better(uint64_t s1, uint32_t i1, uint64_t s2, uint32_t i2) {
+  return s1 > s2 || (s1 == s2 && i1 < i2);  // Candidate.Less inverted, collector.go:20-26
+}
+
+__device__ uint32_t d_lower(const DeviceIndex& ix, uint32_t r) {
+  if (r < 0x80) return (r - 'A' < 26u) ? r + 32 : r;
+  uint32_t lo = 0, hi = ix.n_lower;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (ix.lower_from[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  return (lo < ix.n_lower && ix.lower_from[lo] == r) ? ix.lower_to[lo] : r;
+}
+__device__ __forceinline__ uint32_t d_width(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
+
+// Go `range` decoding of one rune (invalid byte -> U+FFFD, width 1)
+__device__ uint32_t d_next_rune(const uint8_t* s, uint32_t n, uint32_t* adv) {
+  uint32_t c0 = s[0];
+  *adv = 1;
+  if (c0 < 0x80) return c0;
+  if (c0 < 0xC2 || c0 > 0xF4) return kRuneError;
+  if (c0 < 0xE0) {
+    if (n < 2 || (s[1] & 0xC0) != 0x80) return kRuneError;
+    *adv = 2;
+    return ((c0 & 0x1F) << 6) | (s[1] & 0x3F);
+  }
+  if (c0 < 0xF0) {
+    if (n < 3) return kRuneError;
+    uint32_t lo = c0 == 0xE0 ? 0xA0 : 0x80, hi = c0 == 0xED ? 0x9F : 0xBF;
+    if (s[1] < lo || s[1] > hi || (s[2] & 0xC0) != 0x80) return kRuneError;
+    *adv = 3;
+    return ((c0 & 0x0F) << 12) | ((s[1] & 0x3F) << 6) | (s[2] & 0x3F);
+  }
+  if (n < 4) return kRuneError;
+  uint32_t lo = c0 == 0xF0 ? 0x90 : 0x80, hi = c0 == 0xF4 ? 0x8F : 0xBF;
+  if (s[1] < lo || s[1] > hi || (s[2] & 0xC0) != 0x80 || (s[3] & 0xC0) != 0x80) return kRuneError;
+  *adv = 4;
+  return ((c0 & 0x07) << 18) | ((s[1] & 0x3F) << 12) | ((s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+}
+
+// normalizeFilter (normalizer.go:21-37) fused with key packing; n <= 8 runes
+__device__ uint64_t d_pack_key(const DeviceIndex& ix, const uint32_t* runes, uint32_t n) {
+  uint64_t k = 0;
+  uint32_t len = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t r = runes[i];
+    uint32_t id = 0, alpha = 0;
+    if (r < 128) { id = ix.ascii_sym[r]; alpha = ix.ascii_alpha[r]; }
+    else {
+      uint32_t lo = 0, hi = ix.n_na;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (ix.na_rune[mid] < r) lo = mid + 1; else hi = mid; }
+      if (lo < ix.n_na && ix.na_rune[lo] == r) { id = ix.na_sym[lo]; alpha = ix.na_alpha[lo]; }
+    }
+    if (alpha) { k |= (uint64_t)id << (8 * len); len++; }
+    else for (uint32_t p = 0; p < ix.n_pad; p++) { k |= (uint64_t)ix.pad_sym[p] << (8 * len); len++; }
+  }
+  return k;
+}
+
+__device__ uint64_t d_mix64(uint64_t k) {
+  k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
+  k ^= k >> 27; k *= 0x94D049BB133111EBull;
+  k ^= k >> 31;
+  return k;
+}
+__device__ uint32_t d_term_lookup(const DeviceIndex& ix, uint64_t key) {
+  uint32_t h = (uint32_t)d_mix64(key) & ix.slot_mask;
+  for (;;) {
+    TermSlot s = ix.slots[h];
+    if (s.term == kNoTerm) return kNoTerm;
+    if (s.key == key) return s.term;
+    h = (h + 1) & ix.slot_mask;
+  }
+}
+
+// Tokeniser: wrap -> lower -> trim -> q-grams (first-occurrence dedup) -> normalise -> term ids.
+// Returns the token count A (tokens absent from the dictionary keep their slot as kNoTerm), or -1
+// when the query exceeds SG_MAX_A tokens / SG_MAX_RUNES runes.  Wave-uniform control flow.
+__device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
+                          uint32_t* term, int lane) {
+  const DeviceIndex& ix = a.ix;
+  const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete ? 0u : ix.n_wrap1;
+  // ASCII?
+  bool na = false;
+  for (uint32_t i = lane; i < qlen; i += 64) na |= q[i] >= 0x80;
+  const bool ascii = ballot(na) == 0;
+  uint32_t R = 0, byte_len = 0;
+  if (ascii) {
+    R = n_w0 + qlen + n_w1;
+    if (R > SG_MAX_RUNES) return -1;
+    for (uint32_t i = lane; i < R; i += 64) {
+      uint32_t r = i < n_w0 ? ix.wrap0[i] : (i < n_w0 + qlen ? (uint32_t)q[i - n_w0] : ix.wrap1[i - n_w0 - qlen]);
+      runes[i] = d_lower(ix, r);
+    }
+    byte_len = qlen;
+    for (uint32_t i = 0; i < n_w0; i++) byte_len += d_width(d_lower(ix, ix.wrap0[i]));
+    for (uint32_t i = 0; i < n_w1; i++) byte_len += d_width(d_lower(ix, ix.wrap1[i]));
+  } else {
+    // rare path: every lane runs the same sequential decode (uniform), lane 0 stores
+    bool too_long = false;
+    for (uint32_t i = 0; i < n_w0; i++) { uint32_t r = d_lower(ix, ix.wrap0[i]); if (lane == 0) runes[R] = r; R++; byte_len += d_width(r); }
+    uint32_t i = 0;
+    while (i < qlen) {
+      uint32_t adv;
+      uint32_t r = d_lower(ix, d_next_rune(q + i, qlen - i, &adv));
+      i += adv;
+      if (R >= SG_MAX_RUNES - SG_WRAP_MAX) { too_long = true; break; }
+      if (lane == 0) runes[R] = r;
+      R++; byte_len += d_width(r);
+    }
+    if (too_long) return -1;
+    for (uint32_t j = 0; j < n_w1; j++) { uint32_t r = d_lower(ix, ix.wrap1[j]); if (lane == 0) runes[R] = r; R++; byte_len += d_width(r); }
+  }
+  __syncthreads();
+  // strings.Trim(text, " ")
+  uint32_t t0 = 0, t1 = R;
+  while (t0 < t1 && runes[t0] == ' ') { t0++; byte_len--; }
+  while (t1 > t0 && runes[t1 - 1] == ' ') { t1--; byte_len--; }
+  const uint32_t q_n = ix.q;
+  if (byte_len < q_n) return 0;                         // ngram_tokenizer.go:18
+  const uint32_t Rt = t1 - t0;
+  uint32_t n_tok = 0;
+  if (Rt <= q_n) {                                       // one short gram: the whole text
+    if (lane == 0) {
+      uint32_t w[8];
+      for (uint32_t t = 0; t < Rt; t++) w[t] = runes[t0 + t];
+      keys[0] = d_pack_key(ix, w, Rt);
+    }
+    n_tok = 1;
+  } else {
+    const uint32_t G = Rt - q_n + 1;
+    for (uint32_t base = 0; base < G; base += 64) {
+      const uint32_t g = base + lane;
+      const bool valid = g < G;
+      uint32_t w[8];
+      for (uint32_t t = 0; t < q_n; t++) w[t] = valid ? runes[t0 + g + t] : 0u;
+      bool dup = false;                                  // appendUnique, ngram_tokenizer.go:46-54
+      const uint32_t hmax = min(base + 63u, G - 1);
+      for (uint32_t h = 0; h < hmax; h++) {
+        bool eq = true;
+        for (uint32_t t = 0; t < q_n; t++) eq &= runes[t0 + h + t] == w[t];
+        dup |= eq && h < g;
+      }
+      const bool keep = valid && !dup;
+      const uint64_t m = ballot(keep);
+      const uint32_t rank = n_tok + popc64(m & ((1ull << lane) - 1ull));
+      if (keep && rank < SG_MAX_A) keys[rank] = d_pack_key(ix, w, q_n);
+      n_tok += popc64(m);
+    }
+    if (n_tok > SG_MAX_A) return -1;
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < n_tok; i += 64) term[i] = d_term_lookup(ix, keys[i]);
+  __syncthreads();
+  return (int)n_tok;
+}
+
+// inclusive wave scan (64 lanes)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+struct TopK {  // wave-uniform state; arrays live in LDS (k <= SG_K_LDS) or in the query's output row
+  uint64_t* s;
+  uint32_t* id;
+  uint32_t n, k;
+  uint64_t worst_s;
+  uint32_t worst_id, worst_pos;
+};
+
+__device__ void topk_recompute_worst(TopK& tk, int lane) {
+  uint64_t ws = ~0ull; uint32_t wi = 0, wp = 0xFFFFFFFFu;
+  for (uint32_t i = lane; i < tk.n; i += 64) {
+    uint64_t s = tk.s[i]; uint32_t d = tk.id[i];
+    if (wp == 0xFFFFFFFFu || better(ws, wi, s, d)) { ws = s; wi = d; wp = i; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint64_t os = __shfl_xor(ws, off, 64); uint32_t oi = __shfl_xor(wi, off, 64), op = __shfl_xor(wp, off, 64);
+    // pick the worse of the two (ties on (s,id): lower position, for determinism)
+    bool take = op != 0xFFFFFFFFu && (wp == 0xFFFFFFFFu || better(ws, wi, os, oi) || (ws == os && wi == oi && op < wp));
+    if (take) { ws = os; wi = oi; wp = op; }
+  }
+  tk.worst_s = ws; tk.worst_id = wi; tk.worst_pos = wp;
+}
+
+// topKQueue.Add (topk.go:82-102): keep the k best under (score desc, docID asc)
+__device__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
+  if (tk.n < tk.k) {
+    if (lane == 0) { tk.s[tk.n] = s; tk.id[tk.n] = d; }
+    tk.n++;
+    if (tk.n == tk.k) { __syncthreads(); topk_recompute_worst(tk, lane); }
+    return;
+  }
+  if (!better(s, d, tk.worst_s, tk.worst_id)) return;
+  if (lane == 0) { tk.s[tk.worst_pos] = s; tk.id[tk.worst_pos] = d; }
+  __syncthreads();
+  topk_recompute_worst(tk, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
+//   cnt[(1<<log2_nb)/2] u32  (tokeniser scratch aliases it) | term | lstart | lprefix | cand | topk
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x;
+  const uint32_t qi = blockIdx.x;
+  const DeviceIndex& ix = a.ix;
+  const uint32_t cnt_words = (1u << a.log2_nb) >> 1;
+  uint32_t* cnt = smem;
+  uint32_t* term = cnt + cnt_words;
+  uint32_t* lstart = term + SG_MAX_A;
+  uint32_t* lprefix = lstart + SG_MAX_A;           // SG_MAX_A + 1 (+3 pad)
+  uint32_t* cand = lprefix + SG_MAX_A + 4;
+  uint32_t* tk_id_lds = cand + SG_CAND_CAP;
+  uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
+  // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
+  uint32_t* runes = cnt;
+  uint64_t* keys = (uint64_t*)(cnt + SG_MAX_RUNES);
+
+  const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
+  const uint32_t k = a.k;
+  uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
+  double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
+
+  const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
+  if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; return; }
+  if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
+
+  const int S = (int)ix.S;
+  int b_min, b_max;
+  if (a.autocomplete) { b_min = A; b_max = S - 1; }     // autocomplete.go:47
+  else {
+    b_min = d_min_y(a.metric, a.alpha, A);
+    b_max = d_max_y(a.metric, a.alpha, A, S);             // suggester.go:54-59
+    if (b_max >= S) b_max = S - 1;
+    const int span = b_max - b_min + 1;                    // suggester.go:62 make(chan int, span)
+    if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; return; }
+    if (span == 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_DEADLOCK; return; }
+  }
+
+  TopK tk;
+  const bool tk_in_lds = k <= SG_K_LDS;
+  tk.s = tk_in_lds ? tk_s_lds : a.scratch_s + (uint64_t)qi * k;
+  tk.id = tk_in_lds ? tk_id_lds : a.scratch_id + (uint64_t)qi * k;
+  tk.n = 0; tk.k = k; tk.worst_s = 0; tk.worst_id = 0; tk.worst_pos = 0;
+
+  const uint4* post4 = (const uint4*)ix.postings;
+  const int a_rounds = (A + 63) >> 6;
+
+  for (int B = max(b_min, 0); B <= b_max; B++) {
+    int T;
+    if (a.autocomplete) T = A;
+    else {
+      T = d_threshold(a.metric, a.alpha, A, B);
+      if (T == 0 || T > B || T > A) continue;              // suggester.go:76
+    }
+    // ---- posting ranges of the query terms in segment B (searcher.go:38-58) ----
+    __syncthreads();
+    uint32_t running = 0, nonempty = 0;
+    for (int r = 0; r < a_rounds; r++) {
+      const int i = r * 64 + lane;
+      uint32_t s = 0, len = 0;
+      if (i < A) {
+        const uint32_t t = term[i];
+        if (t != kNoTerm) {
+          const uint32_t* so = ix.seg_off + (uint64_t)t * (uint32_t)(S + 1) + (uint32_t)B;
+          s = so[0]; len = so[1] - s;
+        }
+      }
+      const uint32_t incl = wave_scan_incl(len, lane);
+      if (i < A) { lstart[i] = s; lprefix[i] = running + incl - len; }
+      running += readlane(incl, 63);
+      nonempty += popc64(ballot(len != 0));
+    }
+    if (lane == 0) lprefix[A] = running;
+    if ((int)nonempty < T) continue;                        // fewer present terms than T: searcher.go:32
+    const uint32_t L = running;                             // 16-byte chunks to stream
+    // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
+    const bool wide = L >= 16383u;                          // >= 65532 postings: 32-bit counters
+    uint32_t want = L * 8u;                                 // ~2 buckets per posting
+    if (T < 10) want <<= 2;
+    if (T < 6) want <<= 2;
+    uint32_t lg = 8;
+    const uint32_t lg_max = wide ? a.log2_nb - 1 : a.log2_nb;
+    while (lg < lg_max && (1u << lg) < want) lg++;
+    const uint32_t words = wide ? (1u << lg) : (1u << lg) >> 1;
+    for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
+    uint32_t ncand = 0;
+    bool overflow = false;
+    __syncthreads();
+
+    // wave-cooperative exact overlap of doc d in segment B: sum over query-term occurrences
+    auto verify = [&](uint32_t d, int* last_list) -> int {
+      int c = 0, last = -1;
+      for (int r = 0; r < a_rounds; r++) {
+        const int i = r * 64 + lane;
+        bool found = false;
+        if (i < A) {
+          const uint32_t nch = lprefix[i + 1] - lprefix[i];
+          if (nch) {
+            const uint32_t* p = ix.postings + (uint64_t)lstart[i] * 4;
+            uint32_t lo = 0, hi = nch * 4;
+            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
+            found = lo < nch * 4 && p[lo] == d;
+          }
+        }
+        const uint64_t m = ballot(found);
+        c += (int)popc64(m);
+        if (m) last = r * 64 + 63 - __builtin_clzll(m);
+      }
+      *last_list = last;
+      return c;
+    };
+    auto emit = [&](uint32_t d, int overlap) {
+      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
+      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, B)), d, lane);
+    };
+
+    // ---- single streaming pass: count, flag buckets reaching T, verify flagged docs once ----
+    for (uint32_t c0 = 0; c0 < L; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      const bool act = c < L;
+      uint4 v = make_uint4(kPadDoc, kPadDoc, kPadDoc, kPadDoc);
+      if (act) {
+        uint32_t lo = 0, hi = (uint32_t)A;                  // last list j with lprefix[j] <= c
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= c) lo = mid; else hi = mid; }
+        v = post4[lstart[lo] + (c - lprefix[lo])];
+      }
+      const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t d = dv[e];
+        bool flag = false;
+        if (d != kPadDoc) {
+          const uint32_t b = (d * 2654435761u) >> (32 - lg);
+          uint32_t now;
+          if (wide) now = atomicAdd(&cnt[b], 1u) + 1;
+          else {
+            const uint32_t sh = (b & 1u) * 16u;
+            now = ((atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xFFFFu) + 1;
+          }
+          flag = now >= (uint32_t)T;
+        }
+        uint64_t m = ballot(flag);
+        while (m) {                                         // rare; wave-uniform
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t dd = readlane(d, l);
+          bool seen = false;
+          for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
+          if (ballot(seen)) continue;
+          if (ncand == SG_CAND_CAP) { overflow = true; continue; }
+          if (lane == 0) cand[ncand] = dd;
+          ncand++;
+          __syncthreads();
+          int last;
+          const int ov = verify(dd, &last);
+          if (ov >= T) emit(dd, ov);
+        }
+      }
+    }
+    if (overflow) {
+      // More distinct candidates than the dedup set holds: second pass over the final counters;
+      // every doc is handled exactly once, at its occurrence in the last list that contains it.
+      __syncthreads();
+      for (uint32_t c0 = 0; c0 < L; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const bool act = c < L;
+        uint4 v = make_uint4(kPadDoc, kPadDoc, kPadDoc, kPadDoc);
+        uint32_t lo = 0;
+        if (act) {
+          uint32_t hi = (uint32_t)A;
+          while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= c) lo = mid; else hi = mid; }
+          v = post4[lstart[lo] + (c - lprefix[lo])];
+        }
+        const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t d = dv[e];
+          bool flag = false;
+          if (d != kPadDoc) {
+            const uint32_t b = (d * 2654435761u) >> (32 - lg);
+            const uint32_t now = wide ? cnt[b] : ((cnt[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu);
+            flag = now >= (uint32_t)T;
+          }
+          uint64_t m = ballot(flag);
+          while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t dd = readlane(d, l);
+            const int jj = (int)readlane(lo, l);
+            bool seen = false;
+            for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
+            if (ballot(seen)) continue;
+            int last;
+            const int ov = verify(dd, &last);
+            if (last == jj && ov >= T) emit(dd, ov);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- GetCandidates (topk.go:127-147): best first (rank sort, out of place) ----
+  __syncthreads();
+  const uint32_t n = tk.n;
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint64_t s = tk.s[i];
+    const uint32_t d = tk.id[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      const uint64_t sj = tk.s[j];
+      const uint32_t dj = tk.id[j];
+      rank += (better(sj, dj, s, d) || (sj == s && dj == d && j < i)) ? 1u : 0u;
+    }
+    out_ids[rank] = d;
+    if (out_scores) out_scores[rank] = bits_score(s);
+  }
+  if (lane == 0) a.out_counts[qi] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: handle, upload, launches, C ABI
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+
+}  // namespace sg
+
+using namespace sg;
+
+struct sg_index {
+  HostIndex host;
+  std::atomic<int> refs{1};
+  int device = -1;
+  bool uploaded = false;
+  DeviceIndex dix{};
+  std::vector<void*> allocs;
+  uint64_t device_bytes = 0;
+  uint32_t log2_nb = 12;
+};
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+      return SG_E_HIP;                                                                  \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+template <class T>
+int to_device(sg_index* ix, const T* src, size_t n, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+  HIP_TRY(hipMalloc(&p, bytes));
+  ix->allocs.push_back(p);
+  ix->device_bytes += bytes;
+  if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return SG_OK;
+}
+
+struct LowerPair { uint32_t from, to; };
+const LowerPair kLowerPairs[] = {
+#include "unicode_lower.inc"
+};
+
+size_t lds_bytes(uint32_t log2_nb) {
+  size_t words = ((1u << log2_nb) >> 1) + SG_MAX_A * 3 + 4 + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
+  return words * 4;
+}
+
+int check_search_args(sg_index* index, uint32_t k, bool need_alpha, double similarity, int metric) {
+  if (!index) { set_error("null index"); return SG_E_INVALID; }
+  if (!index->uploaded) { set_error("index not uploaded: call sg_index_upload first"); return SG_E_NOT_UPLOADED; }
+  if (k == 0) { set_error("topK should be greater or equal to 1"); return SG_E_INVALID; }       // search.go:20-22
+  if (k > SG_MAX_TOPK) { set_error("topK above SG_MAX_TOPK"); return SG_E_INVALID; }
+  if (need_alpha) {
+    if (!(similarity > 0 && similarity <= 1)) { set_error("similarity shouble be in (0.0, 1.0]"); return SG_E_INVALID; }  // search.go:24-26
+    if (metric < SG_JACCARD || metric > SG_OVERLAP) { set_error("unknown metric"); return SG_E_INVALID; }
+  }
+  return SG_OK;
+}
+
+int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, int metric, double similarity, uint32_t k,
+           int autocomplete, void* d_ids, void* d_scores, void* d_counts, hipStream_t stream) {
+  if (n_q == 0) return SG_OK;
+  BatchArgs a{};
+  a.ix = index->dix;
+  a.q_blob = (const uint8_t*)d_q;
+  a.q_offs = (const uint64_t*)d_offs;
+  a.out_ids = (uint32_t*)d_ids;
+  a.out_scores = (double*)d_scores;
+  a.out_counts = (uint32_t*)d_counts;
+  a.alpha = similarity;
+  a.n_q = n_q;
+  a.k = k;
+  a.metric = metric;
+  a.autocomplete = autocomplete;
+  a.log2_nb = index->log2_nb;
+  void* scratch = nullptr;
+  if (k > SG_K_LDS) {  // top-k working rows in HBM (stream-ordered allocation)
+    HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
+    a.scratch_s = (uint64_t*)scratch;
+    a.scratch_id = (uint32_t*)((char*)scratch + (size_t)n_q * k * 8);
+  }
+  hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_nb), stream, a);
+  HIP_TRY(hipGetLastError());
+  if (scratch) HIP_TRY(hipFreeAsync(scratch, stream));
+  return SG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sg_last_error(void) { return g_err.c_str(); }
+
+int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out) {
+  if (!out || (!utf8 && n_docs) || !offs) { set_error("null argument"); return SG_E_INVALID; }
+  auto* ix = new (std::nothrow) sg_index();
+  if (!ix) return SG_E_NOMEM;
+  std::string err;
+  int rc;
+  try {
+    rc = build_host_index(utf8, offs, n_docs, desc, ix->host, err);
+  } catch (const std::bad_alloc&) { rc = SG_E_NOMEM; err = "out of host memory"; }
+  if (rc) { set_error(err); delete ix; return rc; }
+  if (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX) {
+    set_error("wrap strings longer than 8 runes"); delete ix; return SG_E_UNSUPPORTED;
+  }
+  *out = ix;
+  return SG_OK;
+}
+
+int sg_index_upload(sg_index* ix, int device) {
+  if (!ix) { set_error("null index"); return SG_E_INVALID; }
+  if (ix->uploaded) return SG_OK;
+  HIP_TRY(hipSetDevice(device));
+  const HostIndex& h = ix->host;
+  DeviceIndex& d = ix->dix;
+  int rc;
+  if ((rc = to_device(ix, h.postings.data(), h.postings.size(), &d.postings))) return rc;
+  if ((rc = to_device(ix, h.seg_off.data(), h.seg_off.size(), &d.seg_off))) return rc;
+  if ((rc = to_device(ix, h.slots.data(), h.slots.size(), &d.slots))) return rc;
+  if ((rc = to_device(ix, h.sym.ascii_sym, 128, &d.ascii_sym))) return rc;
+  if ((rc = to_device(ix, h.sym.ascii_alpha, 128, &d.ascii_alpha))) return rc;
+  if ((rc = to_device(ix, h.sym.na_rune.data(), h.sym.na_rune.size(), &d.na_rune))) return rc;
+  if ((rc = to_device(ix, h.sym.na_sym.data(), h.sym.na_sym.size(), &d.na_sym))) return rc;
+  if ((rc = to_device(ix, h.sym.na_alpha.data(), h.sym.na_alpha.size(), &d.na_alpha))) return rc;
+  std::vector<uint32_t> lf, lt;
+  for (const auto& p : kLowerPairs) { lf.push_back(p.from); lt.push_back(p.to); }
+  if ((rc = to_device(ix, lf.data(), lf.size(), &d.lower_from))) return rc;
+  if ((rc = to_device(ix, lt.data(), lt.size(), &d.lower_to))) return rc;
+  d.slot_mask = (uint32_t)h.slots.size() - 1;
+  d.n_na = (uint32_t)h.sym.na_rune.size();
+  d.n_lower = (uint32_t)lf.size();
+  d.S = h.n_segments;
+  d.n_terms = (uint32_t)h.term_key.size();
+  d.q = h.q;
+  d.n_wrap0 = (uint32_t)h.wrap0.size();
+  d.n_wrap1 = (uint32_t)h.wrap1.size();
+  for (size_t i = 0; i < h.wrap0.size(); i++) d.wrap0[i] = h.wrap0[i];
+  for (size_t i = 0; i < h.wrap1.size(); i++) d.wrap1[i] = h.wrap1[i];
+  d.n_pad = h.sym.n_pad;
+  memcpy(d.pad_sym, h.sym.pad_sym, 8);
+  ix->device = device;
+  const char* env = getenv("SG_LOG2_NB");
+  if (env) { int v = atoi(env); if (v >= 10 && v <= 15) ix->log2_nb = (uint32_t)v; }
+  HIP_TRY(hipFuncSetAttribute((const void*)sg_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes(15)));
+  ix->uploaded = true;
+  return SG_OK;
+}
+
+void sg_index_retain(sg_index* ix) { if (ix) ix->refs.fetch_add(1); }
+void sg_index_release(sg_index* ix) {
+  if (!ix) return;
+  if (ix->refs.fetch_sub(1) != 1) return;
+  if (ix->uploaded) { (void)hipSetDevice(ix->device); for (void* p : ix->allocs) (void)hipFree(p); }
+  delete ix;
+}
+
+int sg_suggest_batch_device(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, int metric,
+                            double similarity, uint32_t k, void* d_ids, void* d_scores, void* d_counts, void* stream) {
+  int rc = check_search_args(index, k, true, similarity, metric);
+  if (rc) return rc;
+  return launch(index, d_q, d_offs, n_q, metric, similarity, k, 0, d_ids, d_scores, d_counts, (hipStream_t)stream);
+}
+
+int sg_autocomplete_batch_device(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, uint32_t limit,
+                                 void* d_ids, void* d_counts, void* stream) {
+  int rc = check_search_args(index, limit, false, 0, 0);
+  if (rc) return rc;
+  return launch(index, d_q, d_offs, n_q, 0, 0, limit, 1, d_ids, nullptr, d_counts, (hipStream_t)stream);
+}
+
+static int run_host(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric, double sim,
+                    uint32_t k, int autocomplete, uint32_t* ids, double* scores, uint32_t* counts) {
+  if (n_q == 0) return SG_OK;
+  if (!q && offs[n_q]) { set_error("null query buffer"); return SG_E_INVALID; }
+  HIP_TRY(hipSetDevice(index->device));
+  hipStream_t st;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  void *dq = nullptr, *doffs = nullptr, *dids = nullptr, *dsc = nullptr, *dcnt = nullptr;
+  const size_t qbytes = (size_t)offs[n_q];
+  int rc = SG_OK;
+  auto cleanup = [&]() { (void)hipFree(dq); (void)hipFree(doffs); (void)hipFree(dids); (void)hipFree(dsc); (void)hipFree(dcnt); (void)hipStreamDestroy(st); };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return SG_E_HIP; } } while (0)
+  TRY2(hipMalloc(&dq, std::max<size_t>(qbytes, 16)));
+  TRY2(hipMalloc(&doffs, (size_t)(n_q + 1) * 8));
+  TRY2(hipMalloc(&dids, (size_t)n_q * k * 4));
+  if (!autocomplete) TRY2(hipMalloc(&dsc, (size_t)n_q * k * 8));
+  TRY2(hipMalloc(&dcnt, (size_t)n_q * 4));
+  if (qbytes) TRY2(hipMemcpyAsync(dq, q, qbytes, hipMemcpyHostToDevice, st));
+  TRY2(hipMemcpyAsync(doffs, offs, (size_t)(n_q + 1) * 8, hipMemcpyHostToDevice, st));
+  TRY2(hipMemsetAsync(dids, 0, (size_t)n_q * k * 4, st));
+  if (!autocomplete) TRY2(hipMemsetAsync(dsc, 0, (size_t)n_q * k * 8, st));
+  rc = launch(index, dq, doffs, n_q, metric, sim, k, autocomplete, dids, dsc, dcnt, st);
+  if (rc) { cleanup(); return rc; }
+  TRY2(hipMemcpyAsync(ids, dids, (size_t)n_q * k * 4, hipMemcpyDeviceToHost, st));
+  if (!autocomplete) TRY2(hipMemcpyAsync(scores, dsc, (size_t)n_q * k * 8, hipMemcpyDeviceToHost, st));
+  TRY2(hipMemcpyAsync(counts, dcnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, st));
+  TRY2(hipStreamSynchronize(st));
+#undef TRY2
+  cleanup();
+  return SG_OK;
+}
+
+int sg_suggest_batch(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric, double similarity,
+                     uint32_t k, uint32_t* ids, double* scores, uint32_t* counts) {
+  int rc = check_search_args(index, k, true, similarity, metric);
+  if (rc) return rc;
+  if (!offs || !ids || !scores || !counts) { set_error("null argument"); return SG_E_INVALID; }
+  return run_host(index, q, offs, n_q, metric, similarity, k, 0, ids, scores, counts);
+}
+
+int sg_autocomplete_batch(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, uint32_t limit,
+                          uint32_t* ids, uint32_t* counts) {
+  int rc = check_search_args(index, limit, false, 0, 0);
+  if (rc) return rc;
+  if (!offs || !ids || !counts) { set_error("null argument"); return SG_E_INVALID; }
+  return run_host(index, q, offs, n_q, 0, 0, limit, 1, ids, nullptr, counts);
+}
+
+int sg_index_stats(const sg_index* ix, sg_stats* out) {
+  if (!ix || !out) { set_error("null argument"); return SG_E_INVALID; }
+  const HostIndex& h = ix->host;
+  out->n_docs = h.n_docs; out->n_segments = h.n_segments; out->n_terms = h.term_key.size();
+  out->n_lists = h.n_lists; out->n_postings = h.n_postings; out->n_postings_raw = h.n_postings_raw;
+  out->posting_bytes = h.postings.size() * 4;
+  out->table_bytes = h.seg_off.size() * 4 + h.slots.size() * sizeof(TermSlot);
+  out->device_bytes = ix->device_bytes;
+  return SG_OK;
+}
+
+int sg_tokenize(const sg_index* ix, const uint8_t* text, uint32_t len, int autocomplete, uint64_t* out_keys, uint32_t cap) {
+  if (!ix) { set_error("null index"); return SG_E_INVALID; }
+  std::vector<uint64_t> keys;
+  if (!tokenize_keys(ix->host, text, len, autocomplete != 0, keys)) { set_error("term exceeds the 8-symbol key"); return SG_E_UNSUPPORTED; }
+  for (size_t i = 0; i < keys.size() && i < cap; i++) out_keys[i] = keys[i];
+  return (int)keys.size();
+}
+
+int sg_term_string(const sg_index* ix, uint64_t key, char* out, uint32_t cap) {
+  if (!ix) { set_error("null index"); return SG_E_INVALID; }
+  std::string s;
+  for (int i = 0; i < 8; i++) {
+    uint32_t id = (key >> (8 * i)) & 0xFF;
+    if (!id) break;
+    if (id >= ix->host.sym.sym_rune.size()) { set_error("bad symbol id in key"); return SG_E_INVALID; }
+    uint32_t r = ix->host.sym.sym_rune[id];
+    if (r < 0x80) s.push_back((char)r);
+    else if (r < 0x800) { s.push_back((char)(0xC0 | (r >> 6))); s.push_back((char)(0x80 | (r & 0x3F))); }
+    else if (r < 0x10000) { s.push_back((char)(0xE0 | (r >> 12))); s.push_back((char)(0x80 | ((r >> 6) & 0x3F))); s.push_back((char)(0x80 | (r & 0x3F))); }
+    else { s.push_back((char)(0xF0 | (r >> 18))); s.push_back((char)(0x80 | ((r >> 12) & 0x3F))); s.push_back((char)(0x80 | ((r >> 6) & 0x3F))); s.push_back((char)(0x80 | (r & 0x3F))); }
+  }
+  if (s.size() <= cap) memcpy(out, s.data(), s.size());
+  return (int)s.size();
+}
+
+int64_t sg_index_list(const sg_index* ix, uint32_t segment, uint64_t key, uint32_t* out, uint64_t cap, uint64_t* raw_len) {
+  if (!ix) return -1;
+  const HostIndex& h = ix->host;
+  auto it = h.term_of.find(key);
+  if (it == h.term_of.end() || segment >= h.n_segments) return -1;
+  const size_t t = it->second, S = h.n_segments;
+  const uint32_t len = h.list_len[t * S + segment];
+  if (!len) return -1;
+  const uint32_t* p = h.postings.data() + (size_t)h.seg_off[t * (S + 1) + segment] * 4;
+  for (uint32_t i = 0; i < len && i < cap; i++) out[i] = p[i];
+  if (raw_len) {
+    uint64_t raw = len;
+    DupEntry probe{(uint32_t)t, segment, 0, 0};
+    auto lo = std::lower_bound(h.dups.begin(), h.dups.end(), probe, [](const DupEntry& x, const DupEntry& y) {
+      return x.term != y.term ? x.term < y.term : x.segment < y.segment;
+    });
+    for (; lo != h.dups.end() && lo->term == t && lo->segment == segment; ++lo) raw += lo->mult - 1;
+    *raw_len = raw;
+  }
+  return len;
+}
+
+uint64_t sg_index_lists(const sg_index* ix, uint32_t* out_segments, uint64_t* out_keys, uint64_t cap) {
+  if (!ix) return 0;
+  const HostIndex& h = ix->host;
+  const size_t S = h.n_segments;
+  uint64_t n = 0;
+  for (size_t t = 0; t < h.term_key.size(); t++)
+    for (size_t b = 0; b < S; b++)
+      if (h.list_len[t * S + b]) {
+        if (n < cap) { out_segments[n] = (uint32_t)b; out_keys[n] = h.term_key[t]; }
+        n++;
+      }
+  return n;
+}
+
+int sg_suggest_algorithmic_bytes(const sg_index* ix, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric,
+                                 double similarity, uint32_t k, uint64_t* out_total) {
+  if (!ix || !offs || !out_total) { set_error("null argument"); return SG_E_INVALID; }
+  const HostIndex& h = ix->host;
+  const int S = (int)h.n_segments;
+  uint64_t total = 0;
+  std::vector<uint64_t> keys;
+  for (uint32_t i = 0; i < n_q; i++) {
+    const size_t len = (size_t)(offs[i + 1] - offs[i]);
+    total += len + 12ull * k;
+    if (!tokenize_keys(h, q + offs[i], len, false, keys) || keys.empty()) continue;
+    const int A = (int)keys.size();
+    int b_min = metric_min_y(metric, similarity, A), b_max = metric_max_y(metric, similarity, A);
+    if (b_max >= S) b_max = S - 1;
+    for (int b = std::max(b_min, 0); b <= b_max; b++) {
+      const int T = metric_threshold(metric, similarity, A, b);
+      if (T == 0 || T > b || T > A) continue;
+      for (uint64_t key : keys) {
+        auto it = h.term_of.find(key);
+        if (it != h.term_of.end()) total += 4ull * h.list_len[(size_t)it->second * S + b];
+      }
+    }
+  }
+  *out_total = total;
+  return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+// host_index.cpp — host side of libsuggest_hip: tokenizer, term-key packing and the CSR index
+// builder.  Replaces (for the GPU engine) the reference's
+//   NewSuggestTokenizer        pkg/suggest/tokenizer.go:9-34 (+ pkg/analysis, pkg/alphabet)
+//   suggest.Index              pkg/suggest/indexer.go:14-45
+//   Writer.AddDocument/Commit  pkg/index/indexer_writer.go:66-145
+// Layout decisions are in DESIGN.md §Data layout.  No code here is shared with the test oracle.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "sg_internal.h"
+
+namespace sg {
+
+namespace {
+
+struct LowerPair { uint32_t from, to; };
+const LowerPair kLower[] = {
+#include "unicode_lower.inc"
+};
+
+// Go `range` decoding: invalid byte -> U+FFFD, width 1
+inline uint32_t next_rune(const uint8_t* s, size_t n, size_t* adv) {
+  uint32_t c0 = s[0];
+  *adv = 1;
+  if (c0 < 0x80) return c0;
+  if (c0 < 0xC2 || c0 > 0xF4) return kRuneError;
+  if (c0 < 0xE0) {
+    if (n < 2 || (s[1] & 0xC0) != 0x80) return kRuneError;
+    *adv = 2;
+    return ((c0 & 0x1F) << 6) | (s[1] & 0x3F);
+  }
+  if (c0 < 0xF0) {
+    if (n < 3) return kRuneError;
+    uint32_t lo = c0 == 0xE0 ? 0xA0 : 0x80, hi = c0 == 0xED ? 0x9F : 0xBF;
+    if (s[1] < lo || s[1] > hi || (s[2] & 0xC0) != 0x80) return kRuneError;
+    *adv = 3;
+    return ((c0 & 0x0F) << 12) | ((s[1] & 0x3F) << 6) | (s[2] & 0x3F);
+  }
+  if (n < 4) return kRuneError;
+  uint32_t lo = c0 == 0xF0 ? 0x90 : 0x80, hi = c0 == 0xF4 ? 0x8F : 0xBF;
+  if (s[1] < lo || s[1] > hi || (s[2] & 0xC0) != 0x80 || (s[3] & 0xC0) != 0x80) return kRuneError;
+  *adv = 4;
+  return ((c0 & 0x07) << 18) | ((s[1] & 0x3F) << 12) | ((s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+}
+
+inline uint32_t utf8_width(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
+
+inline uint32_t lower_rune(uint32_t r) {
+  if (r < 0x80) return (r - 'A' < 26u) ? r + 32 : r;
+  size_t lo = 0, hi = SG_UNICODE_LOWER_COUNT;
+  while (lo < hi) {
+    size_t mid = (lo + hi) >> 1;
+    if (kLower[mid].from < r) lo = mid + 1; else hi = mid;
+  }
+  return (lo < SG_UNICODE_LOWER_COUNT && kLower[lo].from == r) ? kLower[lo].to : r;
+}
+
+void decode_all(const std::string& s, std::vector<uint32_t>& out) {
+  size_t i = 0;
+  while (i < s.size()) {
+    size_t adv;
+    out.push_back(next_rune((const uint8_t*)s.data() + i, s.size() - i, &adv));
+    i += adv;
+  }
+}
+
+inline void sym_lookup(const Symbols& sy, uint32_t r, uint8_t* id, bool* alpha) {
+  if (r < 128) { *id = sy.ascii_sym[r]; *alpha = sy.ascii_alpha[r] != 0; return; }
+  auto it = std::lower_bound(sy.na_rune.begin(), sy.na_rune.end(), r);
+  if (it != sy.na_rune.end() && *it == r) {
+    size_t k = it - sy.na_rune.begin();
+    *id = sy.na_sym[k]; *alpha = sy.na_alpha[k] != 0;
+  } else { *id = 0; *alpha = false; }
+}
+
+// normaliseFilter (pkg/analysis/normalizer.go:21-37) fused with key packing
+inline bool pack_key(const Symbols& sy, const uint32_t* runes, uint32_t n, uint64_t* key) {
+  uint64_t k = 0;
+  uint32_t len = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    uint8_t id; bool alpha;
+    sym_lookup(sy, runes[i], &id, &alpha);
+    if (alpha) {
+      if (len >= 8) return false;
+      k |= (uint64_t)id << (8 * len++);
+    } else {
+      for (uint32_t p = 0; p < sy.n_pad; p++) {
+        if (len >= 8) return false;
+        k |= (uint64_t)sy.pad_sym[p] << (8 * len++);
+      }
+    }
+  }
+  *key = k;
+  return true;
+}
+
+bool alphabet_part_has(const std::string& spec, uint32_t r) {
+  // pkg/alphabet/alphabet.go:23-36 + sequential/simple/russian alphabets
+  if (spec == "english") return r >= 'a' && r <= 'z';
+  if (spec == "numbers") return r >= '0' && r <= '9';
+  if (spec == "russian") { uint32_t c = r == 0x451 ? 0x435 : r; return c >= 0x430 && c <= 0x44F; }
+  std::vector<uint32_t> rs; decode_all(spec, rs);
+  return std::find(rs.begin(), rs.end(), r) != rs.end();
+}
+
+int build_symbols(HostIndex& ix, std::string& err) {
+  std::vector<uint32_t> alpha_runes;
+  for (const auto& spec : ix.alphabet_spec) {
+    if (spec == "english") for (uint32_t r = 'a'; r <= 'z'; r++) alpha_runes.push_back(r);
+    else if (spec == "numbers") for (uint32_t r = '0'; r <= '9'; r++) alpha_runes.push_back(r);
+    else if (spec == "russian") { for (uint32_t r = 0x430; r <= 0x44F; r++) alpha_runes.push_back(r); alpha_runes.push_back(0x451); }
+    else decode_all(spec, alpha_runes);
+  }
+  std::vector<uint32_t> pad_runes; decode_all(ix.pad_s, pad_runes);
+  std::vector<uint32_t> all = alpha_runes;
+  all.insert(all.end(), pad_runes.begin(), pad_runes.end());
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  if (all.size() > 255) { err = "alphabet + pad have more than 255 distinct runes"; return SG_E_UNSUPPORTED; }
+  if (pad_runes.size() > 8 || ix.q * std::max<size_t>(1, pad_runes.size()) > 8) {
+    err = "ngram_size * len(pad runes) exceeds the 8-symbol term key"; return SG_E_UNSUPPORTED;
+  }
+  Symbols& sy = ix.sym;
+  memset(sy.ascii_sym, 0, sizeof sy.ascii_sym);
+  memset(sy.ascii_alpha, 0, sizeof sy.ascii_alpha);
+  sy.sym_rune.assign(1, 0);
+  std::sort(alpha_runes.begin(), alpha_runes.end());
+  for (size_t i = 0; i < all.size(); i++) {
+    uint32_t r = all[i];
+    uint8_t id = (uint8_t)(i + 1);
+    bool in_alpha = std::binary_search(alpha_runes.begin(), alpha_runes.end(), r);
+    sy.sym_rune.push_back(r);
+    if (r < 128) { sy.ascii_sym[r] = id; sy.ascii_alpha[r] = in_alpha; }
+    else { sy.na_rune.push_back(r); sy.na_sym.push_back(id); sy.na_alpha.push_back(in_alpha); }
+  }
+  sy.n_pad = (uint32_t)pad_runes.size();
+  for (size_t i = 0; i < pad_runes.size(); i++) { uint8_t id; bool a; sym_lookup(sy, pad_runes[i], &id, &a); sy.pad_sym[i] = id; }
+  return SG_OK;
+}
+
+}  // namespace
+
+uint64_t mix64(uint64_t k) {  // splitmix64 finaliser
+  k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
+  k ^= k >> 27; k *= 0x94D049BB133111EBull;
+  k ^= k >> 31;
+  return k;
+}
+
+int metric_min_y(int m, double alpha, int size) {
+  switch (m) {
+    case SG_JACCARD: return (int)std::ceil(alpha * (double)size);                 // jaccard.go:12-14
+    case SG_COSINE: return (int)std::ceil(alpha * alpha * (double)size);          // cosine.go:12-14
+    case SG_DICE: return (int)std::ceil(alpha / (2 - alpha) * (double)size);      // dice.go:12-14
+    case SG_EXACT: return size;
+    default: return 1;
+  }
+}
+int metric_max_y(int m, double alpha, int size) {
+  switch (m) {
+    case SG_JACCARD: return (int)std::floor((double)size / alpha);
+    case SG_COSINE: return (int)std::floor((double)size / (alpha * alpha));
+    case SG_DICE: return (int)std::floor((2 - alpha) / alpha * (double)size);
+    case SG_EXACT: return size;
+    default: return 32767;
+  }
+}
+int metric_threshold(int m, double alpha, int a, int b) {
+  switch (m) {
+    case SG_JACCARD: return (int)std::ceil(alpha * (double)(a + b) / (1 + alpha));
+    case SG_COSINE: return (int)std::ceil(alpha * std::sqrt((double)(a * b)));
+    case SG_DICE: return (int)std::ceil(0.5 * alpha * (double)(a + b));
+    case SG_EXACT: return a;
+    default: return (int)std::ceil(alpha * std::fmin((double)a, (double)b));
+  }
+}
+
+// wrap -> lower -> trim -> q-gram (first-occurrence dedup) -> normalise, as packed keys
+bool tokenize_keys(const HostIndex& ix, const uint8_t* s, size_t n, bool autocomplete, std::vector<uint64_t>& out) {
+  out.clear();
+  const uint32_t q = ix.q;
+  thread_local std::vector<uint32_t> runes;
+  runes.clear();
+  bool ascii = true;
+  for (size_t i = 0; i < n; i++) if (s[i] >= 0x80) { ascii = false; break; }
+  // wrap symbols are stored as runes already; they take part in lower-casing like the text
+  for (uint32_t r : ix.wrap0) runes.push_back(r);
+  if (ascii) {
+    for (size_t i = 0; i < n; i++) runes.push_back(s[i]);
+  } else {
+    size_t i = 0;
+    while (i < n) { size_t adv; runes.push_back(next_rune(s + i, n - i, &adv)); i += adv; }
+  }
+  if (!autocomplete) for (uint32_t r : ix.wrap1) runes.push_back(r);
+  size_t byte_len = 0;
+  for (auto& r : runes) { r = lower_rune(r); byte_len += utf8_width(r); }
+  // strings.Trim(text, " ")
+  size_t a = 0, b = runes.size();
+  while (a < b && runes[a] == ' ') { a++; byte_len--; }
+  while (b > a && runes[b - 1] == ' ') { b--; byte_len--; }
+  if (byte_len < q) return true;                       // ngram_tokenizer.go:18
+  const uint32_t* r = runes.data() + a;
+  size_t R = b - a;
+  if (R <= q) {                                        // fewer runes than q: the whole text, once
+    uint64_t key;
+    if (!pack_key(ix.sym, r, (uint32_t)R, &key)) return false;
+    out.push_back(key);
+    return true;
+  }
+  size_t G = R - q + 1;
+  for (size_t g = 0; g < G; g++) {
+    bool dup = false;                                  // appendUnique, ngram_tokenizer.go:46-54
+    for (size_t h = 0; h < g && !dup; h++) {
+      bool eq = true;
+      for (uint32_t t = 0; t < q; t++) if (r[h + t] != r[g + t]) { eq = false; break; }
+      dup = eq;
+    }
+    if (dup) continue;
+    uint64_t key;
+    if (!pack_key(ix.sym, r + g, q, &key)) return false;
+    out.push_back(key);
+  }
+  return true;
+}
+
+int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
+                     std::string& err) {
+  if (!desc || desc->ngram_size < 1 || desc->ngram_size > 8) { err = "ngram_size must be in 1..8"; return SG_E_INVALID; }
+  ix.q = desc->ngram_size;
+  ix.wrap0_s = desc->wrap_start ? desc->wrap_start : "";
+  ix.wrap1_s = desc->wrap_end ? desc->wrap_end : "";
+  ix.pad_s = desc->pad ? desc->pad : "";
+  for (uint32_t i = 0; i < desc->n_alphabet; i++) ix.alphabet_spec.emplace_back(desc->alphabet[i]);
+  decode_all(ix.wrap0_s, ix.wrap0);
+  decode_all(ix.wrap1_s, ix.wrap1);
+  int rc = build_symbols(ix, err);
+  if (rc) return rc;
+  ix.n_docs = n_docs;
+
+  // pass 1: tokenise, intern terms, remember each doc's (de-duplicated) term ids and cardinality
+  std::vector<uint32_t> doc_terms;       // unique term ids per doc, concatenated
+  std::vector<uint64_t> doc_off(n_docs + 1, 0);
+  std::vector<uint32_t> doc_card(n_docs);
+  doc_terms.reserve((size_t)n_docs * 16);
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> tids;
+  uint32_t max_card = 0;
+  struct RawDup { uint32_t doc, term, mult; };
+  std::vector<RawDup> raw_dups;
+  ix.term_of.reserve(1 << 16);
+  for (uint32_t d = 0; d < n_docs; d++) {
+    if (!tokenize_keys(ix, utf8 + offs[d], (size_t)(offs[d + 1] - offs[d]), false, keys)) {
+      err = "a term does not fit the 8-symbol key"; return SG_E_UNSUPPORTED;
+    }
+    uint32_t card = (uint32_t)keys.size();
+    doc_card[d] = card;
+    max_card = std::max(max_card, card);
+    tids.clear();
+    for (uint64_t k : keys) {
+      auto it = ix.term_of.find(k);
+      uint32_t t;
+      if (it == ix.term_of.end()) { t = (uint32_t)ix.term_key.size(); ix.term_key.push_back(k); ix.term_of.emplace(k, t); }
+      else t = it->second;
+      tids.push_back(t);
+    }
+    ix.n_postings_raw += card;
+    // a doc may repeat a term after normalisation; the CSR keeps (term,doc) once
+    bool has_dup = false;
+    for (size_t i = 1; i < tids.size() && !has_dup; i++)
+      for (size_t j = 0; j < i; j++) if (tids[i] == tids[j]) { has_dup = true; break; }
+    if (has_dup) {
+      std::vector<uint32_t> sorted = tids;
+      std::sort(sorted.begin(), sorted.end());
+      tids.clear();
+      for (size_t i = 0; i < sorted.size();) {
+        size_t j = i;
+        while (j < sorted.size() && sorted[j] == sorted[i]) j++;
+        tids.push_back(sorted[i]);
+        if (j - i > 1) raw_dups.push_back(RawDup{d, sorted[i], (uint32_t)(j - i)});
+        i = j;
+      }
+    }
+    doc_terms.insert(doc_terms.end(), tids.begin(), tids.end());
+    doc_off[d + 1] = doc_terms.size();
+  }
+  // indexer_writer.go:69-73: len(indices) = max cardinality + 1
+  const uint32_t S = n_docs ? max_card + 1 : 0;
+  ix.n_segments = S;
+  const size_t nT = ix.term_key.size();
+  ix.n_postings = doc_terms.size();
+
+  // pass 2: count per (term, segment), lay the lists out term-major, each padded to 4 postings
+  ix.list_len.assign(nT * (size_t)S, 0);
+  for (uint32_t d = 0; d < n_docs; d++)
+    for (uint64_t p = doc_off[d]; p < doc_off[d + 1]; p++) ix.list_len[(size_t)doc_terms[p] * S + doc_card[d]]++;
+  ix.seg_off.assign(nT * (size_t)(S + 1) + 1, 0);
+  uint64_t chunk = 0;
+  for (size_t t = 0; t < nT; t++) {
+    for (uint32_t b = 0; b < S; b++) {
+      ix.seg_off[t * (S + 1) + b] = (uint32_t)chunk;
+      uint32_t len = ix.list_len[t * S + b];
+      if (len) ix.n_lists++;
+      chunk += (len + 3) / 4;
+    }
+    ix.seg_off[t * (S + 1) + S] = (uint32_t)chunk;
+    if (chunk >= 0xFFFFFFF0ull) { err = "posting store exceeds 2^32 16-byte chunks"; return SG_E_UNSUPPORTED; }
+  }
+  ix.postings.assign((size_t)chunk * 4, kPadDoc);
+  std::vector<uint32_t> cursor(nT * (size_t)S, 0);
+  for (uint32_t d = 0; d < n_docs; d++) {           // ascending docID => every list ascending
+    uint32_t b = doc_card[d];
+    for (uint64_t p = doc_off[d]; p < doc_off[d + 1]; p++) {
+      size_t t = doc_terms[p];
+      ix.postings[(size_t)ix.seg_off[t * (S + 1) + b] * 4 + cursor[t * S + b]++] = d;
+    }
+  }
+  for (const auto& rd : raw_dups) ix.dups.push_back(DupEntry{rd.term, doc_card[rd.doc], rd.doc, rd.mult});
+  std::sort(ix.dups.begin(), ix.dups.end(), [](const DupEntry& x, const DupEntry& y) {
+    if (x.term != y.term) return x.term < y.term;
+    if (x.segment != y.segment) return x.segment < y.segment;
+    return x.doc < y.doc;
+  });
+
+  // term-key hash table (open addressing, linear probing, load <= 0.5)
+  size_t cap = 16;
+  while (cap < nT * 2) cap <<= 1;
+  ix.slots.assign(cap, TermSlot{0, kNoTerm, 0});
+  for (size_t t = 0; t < nT; t++) {
+    size_t h = mix64(ix.term_key[t]) & (cap - 1);
+    while (ix.slots[h].term != kNoTerm) h = (h + 1) & (cap - 1);
+    ix.slots[h] = TermSlot{ix.term_key[t], (uint32_t)t, 0};
+  }
+  return SG_OK;
+}
+
+}  // namespace sg

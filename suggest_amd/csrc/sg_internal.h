@@ -1,0 +1,79 @@
+// sg_internal.h — structures shared by the host index builder (host_index.cpp) and the
+// HIP engine (engine.hip).  Not part of the public ABI (include/suggest_hip.h).
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/suggest_hip.h"
+
+namespace sg {
+
+constexpr uint32_t kNoTerm = 0xFFFFFFFFu;
+constexpr uint32_t kPadDoc = 0xFFFFFFFFu;  // sentinel that pads every posting list to 16 bytes
+constexpr uint32_t kRuneError = 0xFFFD;
+
+// Symbol table: every rune that can appear in a normalised term (alphabet runes + the runes of
+// the pad string) gets an id 1..255; a term is at most 8 symbols and is packed little-endian
+// into a u64 (byte i = symbol i, 0 = end).  Key equality == reference term-string equality.
+struct Symbols {
+  uint8_t ascii_sym[128];    // symbol id of an ASCII rune, 0 = not a symbol
+  uint8_t ascii_alpha[128];  // 1 = Alphabet.Has(rune)
+  std::vector<uint32_t> na_rune;  // non-ASCII symbol runes, ascending
+  std::vector<uint8_t> na_sym, na_alpha;
+  uint8_t pad_sym[8];
+  uint32_t n_pad = 0;
+  std::vector<uint32_t> sym_rune;  // id -> rune (index 0 unused)
+};
+
+struct TermSlot {  // open-addressing hash table slot (16 B)
+  uint64_t key;
+  uint32_t term;  // kNoTerm = empty
+  uint32_t pad;
+};
+
+struct DupEntry {  // a (term, segment, doc) whose doc repeats the term
+  uint32_t term, segment, doc, mult;
+};
+
+struct HostIndex {
+  // description
+  uint32_t q = 3;
+  std::vector<uint32_t> wrap0, wrap1;  // runes
+  std::string wrap0_s, wrap1_s, pad_s;
+  std::vector<std::string> alphabet_spec;
+  Symbols sym;
+
+  uint64_t n_docs = 0;
+  uint32_t n_segments = 0;  // == header.Indices of the reference (max cardinality + 1)
+  std::vector<uint64_t> term_key;                    // termID -> key
+  std::unordered_map<uint64_t, uint32_t> term_of;    // key -> termID
+  std::vector<uint32_t> seg_off;                     // [n_terms*(S+1)] chunk (16 B) offsets, term-major
+  std::vector<uint32_t> list_len;                    // [n_terms*S] stored (de-duplicated) lengths
+  std::vector<uint32_t> postings;                    // padded chunks, ascending docIDs per (term, segment)
+  std::vector<DupEntry> dups;                        // docs with repeated terms, ascending (term, segment, doc)
+  std::vector<TermSlot> slots;                       // hash table, size = power of two
+  uint64_t n_lists = 0, n_postings = 0, n_postings_raw = 0;
+};
+
+// host tokenizer (NewSuggestTokenizer / NewAutocompleteTokenizer, pkg/suggest/tokenizer.go:9-34)
+// -> packed term keys, repeats included, first-occurrence order.  Returns false if a term does
+// not fit the 8-symbol key.
+bool tokenize_keys(const HostIndex& ix, const uint8_t* s, size_t n, bool autocomplete, std::vector<uint64_t>& out);
+
+int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
+                     std::string& err);
+
+// metric maths in IEEE double, evaluation order of pkg/metric/*.go (host copies; engine.hip has
+// the device twins)
+int metric_min_y(int m, double alpha, int size);
+int metric_max_y(int m, double alpha, int size);
+int metric_threshold(int m, double alpha, int a, int b);
+
+uint64_t mix64(uint64_t k);
+void set_error(const std::string& msg);
+
+}  // namespace sg

@@ -1,0 +1,178 @@
+"""NGramIndex on the GPU: host CSR build + HBM replica + batched Suggest / Autocomplete.
+
+Mirrors suggest.Builder / suggest.NGramIndex (pkg/suggest/ngram_index_builder.go:14-83, ngram_index.go:7-35)
+for the hot path; every call goes through the C ABI of include/suggest_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .metric import resolve
+
+
+def pack_strings(strings):
+    """list[str|bytes] -> (uint8 blob, uint64 offsets[n+1])"""
+    bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strings]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return blob, offs
+
+
+class IndexDescription:
+    """pkg/suggest/config.go:25-35"""
+
+    def __init__(self, name="index", ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "numbers", "$"),
+                 driver="RAM", source=None, output=None):
+        self.name, self.ngram_size, self.wrap, self.pad = name, int(ngram_size), tuple(wrap), pad
+        self.alphabet, self.driver, self.source, self.output = tuple(alphabet), driver, source, output
+
+    @classmethod
+    def from_json(cls, d):
+        return cls(name=d.get("name", "index"), ngram_size=d["nGramSize"], wrap=tuple(d["wrap"]), pad=d["pad"],
+                   alphabet=tuple(d["alphabet"]), driver=d.get("driver", "RAM"), source=d.get("source"), output=d.get("output"))
+
+
+def _enc(s):
+    return s.encode("utf-8") if isinstance(s, str) else bytes(s)
+
+
+class NGramIndex:
+    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True):
+        L = _lib.lib()
+        d = description or IndexDescription()
+        self.description = d
+        if blob is None:
+            blob, offs = pack_strings(docs)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        self.n_docs = len(offs) - 1
+        alpha = (C.c_char_p * len(d.alphabet))(*[_enc(a) for a in d.alphabet])
+        desc = _lib.SgDesc(d.ngram_size, _enc(d.wrap[0]), _enc(d.wrap[1]), _enc(d.pad), alpha, len(d.alphabet))
+        h = C.c_void_p()
+        _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
+        self._h = h
+        self.device = None
+        if upload:
+            self.upload(device)
+
+    def upload(self, device=0):
+        _lib.check(_lib.lib().sg_index_upload(self._h, int(device)))
+        self.device = int(device)
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sg_index_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- search: host buffers ------------------------------------------------------------
+    def suggest_batch(self, queries=None, metric="jaccard", similarity=0.5, k=10, blob=None, offs=None):
+        """-> (ids[n_q,k] u32, scores[n_q,k] f64, counts[n_q] u32); row i best first."""
+        if blob is None:
+            blob, offs = pack_strings(queries)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n_q = len(offs) - 1
+        ids = np.zeros((n_q, k), dtype=np.uint32)
+        sc = np.zeros((n_q, k), dtype=np.float64)
+        cnt = np.zeros(n_q, dtype=np.uint32)
+        _lib.check(_lib.lib().sg_suggest_batch(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q,
+                                               resolve(metric).code, float(similarity), int(k), ids.ctypes.data, sc.ctypes.data,
+                                               cnt.ctypes.data))
+        return ids, sc, cnt
+
+    def autocomplete_batch(self, queries=None, limit=10, blob=None, offs=None):
+        if blob is None:
+            blob, offs = pack_strings(queries)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n_q = len(offs) - 1
+        ids = np.zeros((n_q, limit), dtype=np.uint32)
+        cnt = np.zeros(n_q, dtype=np.uint32)
+        _lib.check(_lib.lib().sg_autocomplete_batch(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q,
+                                                    int(limit), ids.ctypes.data, cnt.ctypes.data))
+        return ids, cnt
+
+    # ---- search: device-resident buffers (raw pointers; torch tensors' data_ptr()) ---------
+    def suggest_batch_device(self, d_blob, d_offs, n_q, metric, similarity, k, d_ids, d_scores, d_counts, stream=0):
+        _lib.check(_lib.lib().sg_suggest_batch_device(self._h, d_blob, d_offs, int(n_q), resolve(metric).code, float(similarity),
+                                                      int(k), d_ids, d_scores, d_counts, stream))
+
+    def autocomplete_batch_device(self, d_blob, d_offs, n_q, limit, d_ids, d_counts, stream=0):
+        _lib.check(_lib.lib().sg_autocomplete_batch_device(self._h, d_blob, d_offs, int(n_q), int(limit), d_ids, d_counts, stream))
+
+    # ---- NGramIndex interface (single query) -----------------------------------------------
+    def suggest(self, query, similarity, metric, k):
+        """Suggester.Suggest (pkg/suggest/suggester.go:17-20) -> list[(docID, score)] best first."""
+        ids, sc, cnt = self.suggest_batch([query], metric, similarity, k)
+        c = int(cnt[0])
+        if c == _lib.SG_COUNT_REF_PANIC:
+            raise RuntimeError("query window is empty: the reference panics here (suggester.go:62, negative channel capacity)")
+        if c == _lib.SG_COUNT_REF_DEADLOCK:
+            raise RuntimeError("query window is empty: the reference dead-locks here (suggester.go:62, zero channel capacity)")
+        if c == _lib.SG_COUNT_TOO_LONG:
+            raise ValueError("query has more than %d n-grams" % _lib.SG_MAX_QUERY_TERMS)
+        return [(int(ids[0, i]), float(sc[0, i])) for i in range(c)]
+
+    def autocomplete(self, query, limit):
+        ids, cnt = self.autocomplete_batch([query], limit)
+        c = int(cnt[0])
+        if c == _lib.SG_COUNT_TOO_LONG:
+            raise ValueError("query has more than %d n-grams" % _lib.SG_MAX_QUERY_TERMS)
+        return [int(ids[0, i]) for i in range(c)]
+
+    # ---- introspection ---------------------------------------------------------------------
+    def stats(self):
+        st = _lib.SgStats()
+        _lib.check(_lib.lib().sg_index_stats(self._h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def tokenize_keys(self, text, autocomplete=False):
+        t = _enc(text)
+        cap = 4 * len(t) + 64
+        buf = np.zeros(cap, dtype=np.uint64)
+        n = _lib.check(_lib.lib().sg_tokenize(self._h, t, len(t), 1 if autocomplete else 0, buf.ctypes.data, cap))
+        return [int(x) for x in buf[:n]]
+
+    def term_string(self, key):
+        buf = C.create_string_buffer(64)
+        n = _lib.check(_lib.lib().sg_term_string(self._h, int(key), buf, 64))
+        return buf.raw[:n]
+
+    def tokenize(self, text, autocomplete=False):
+        return [self.term_string(k) for k in self.tokenize_keys(text, autocomplete)]
+
+    def lists(self):
+        """-> {(segment, term_bytes): (raw_len, [stored docIDs])} from the host CSR"""
+        L = _lib.lib()
+        n = L.sg_index_lists(self._h, None, None, 0)
+        segs = np.zeros(n, dtype=np.uint32)
+        keys = np.zeros(n, dtype=np.uint64)
+        L.sg_index_lists(self._h, segs.ctypes.data, keys.ctypes.data, n)
+        out = {}
+        raw = C.c_uint64()
+        buf = np.zeros(1 << 16, dtype=np.uint32)
+        for s, k in zip(segs.tolist(), keys.tolist()):
+            ln = L.sg_index_list(self._h, s, k, buf.ctypes.data, buf.size, C.byref(raw))
+            if ln > buf.size:
+                buf = np.zeros(int(ln), dtype=np.uint32)
+                ln = L.sg_index_list(self._h, s, k, buf.ctypes.data, buf.size, C.byref(raw))
+            out[(s, self.term_string(k))] = (int(raw.value), buf[:ln].tolist())
+        return out
+
+    def algorithmic_bytes(self, blob, offs, metric, similarity, k):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        out = C.c_uint64()
+        _lib.check(_lib.lib().sg_suggest_algorithmic_bytes(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data,
+                                                           len(offs) - 1, resolve(metric).code, float(similarity), int(k), C.byref(out)))
+        return int(out.value)

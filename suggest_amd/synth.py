@@ -1,0 +1,80 @@
+"""Deterministic synthetic workloads of BASELINE.json / SURVEY.md §8(d).
+
+Counter-based splitmix64: draw(seed, i, j) = mix(seed * 0x9E3779B97F4A7C15 + i * 64 + j), so the
+generator vectorises and any slice of the dictionary can be produced independently.
+  dict(N, seed=1):   doc i has length 8 + draw(seed,i,0) % 25 over [a-z0-9] (chars draw(seed,i,1+j) % 36)
+  queries(M, seed=2): query q = doc draw(seed,q,0) % N with 1 + draw(seed,q,1) % 2 random edits
+                      (substitute / delete / insert at a random position, random symbol)
+Normalisation is the identity on this alphabet, so no document repeats a term.
+"""
+import numpy as np
+
+ALPHABET = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
+DESCRIPTION = dict(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "numbers", "$"))
+_G = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix(x):
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def draw(seed, i, j):
+    with np.errstate(over="ignore"):
+        return _mix(np.uint64(seed) * _G + np.asarray(i, dtype=np.uint64) * np.uint64(64) + np.asarray(j, dtype=np.uint64))
+
+
+def make_dict(n, seed=1, chunk=1 << 20):
+    """-> (blob uint8, offs uint64[n+1])"""
+    lens = np.empty(n, dtype=np.int64)
+    parts = []
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        idx = np.arange(s, e, dtype=np.uint64)
+        L = 8 + (draw(seed, idx, 0) % np.uint64(25)).astype(np.int64)
+        lens[s:e] = L
+        j = np.arange(32, dtype=np.uint64)
+        ch = ALPHABET[(draw(seed, idx[:, None], j[None, :] + np.uint64(1)) % np.uint64(36)).astype(np.int64)]
+        mask = np.arange(32)[None, :] < L[:, None]
+        parts.append(ch[mask])
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens).astype(np.uint64)
+    return (np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)), offs
+
+
+def make_queries(m, blob, offs, seed=2, start=0):
+    """-> (blob uint8, offs uint64[m+1]); query ids start..start+m-1 (lets ranks draw disjoint batches)"""
+    n = len(offs) - 1
+    qi = np.arange(start, start + m, dtype=np.uint64)
+    docs = (draw(seed, qi, 0) % np.uint64(n)).astype(np.int64)
+    n_edits = 1 + (draw(seed, qi, 1) % np.uint64(2)).astype(np.int64)
+    r = draw(seed, qi[:, None], np.arange(2, 10, dtype=np.uint64)[None, :])
+    out = []
+    offs_i = offs.astype(np.int64)
+    for q in range(m):
+        s = bytearray(blob[offs_i[docs[q]]:offs_i[docs[q] + 1]].tobytes())
+        for e in range(int(n_edits[q])):
+            kind = int(r[q, 3 * e] % np.uint64(3))
+            sym = int(ALPHABET[int(r[q, 3 * e + 2] % np.uint64(36))])
+            if kind == 0 and s:
+                s[int(r[q, 3 * e + 1] % np.uint64(len(s)))] = sym
+            elif kind == 1 and len(s) > 1:
+                del s[int(r[q, 3 * e + 1] % np.uint64(len(s)))]
+            else:
+                s.insert(int(r[q, 3 * e + 1] % np.uint64(len(s) + 1)), sym)
+        out.append(bytes(s))
+    qoffs = np.zeros(m + 1, dtype=np.uint64)
+    qoffs[1:] = np.cumsum([len(x) for x in out]).astype(np.uint64)
+    return np.frombuffer(b"".join(out), dtype=np.uint8).copy(), qoffs
+
+
+def unpack(blob, offs):
+    o = offs.astype(np.int64)
+    b = blob.tobytes()
+    return [b[o[i]:o[i + 1]] for i in range(len(o) - 1)]

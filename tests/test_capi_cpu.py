@@ -1,0 +1,102 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every declared symbol,
+the host tokenizer and CSR builder agree with the oracle and with the reference's index files."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import refindex
+from conftest import CARS_DESC, WORDS_DESC, GOLDEN, ROOT
+
+
+def _desc(d):
+    from suggest_amd import IndexDescription
+    return IndexDescription(ngram_size=d["ngram_size"], wrap=d["wrap"], pad=d["pad"], alphabet=d["alphabet"])
+
+
+def test_library_exports_every_declared_symbol():
+    from suggest_amd import _lib
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "suggest_hip.h")).read()
+    declared = set(re.findall(r"\b(sg_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_product_does_not_touch_the_oracle():
+    # the product path must not import, link, include or call anything under oracle/
+    pat = re.compile(r"import\s+oracle|from\s+oracle|liboracle|oracle/|suggest_oracle|or_suggest|or_index")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "suggest_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not pat.search(text), (f, pat.search(text).group(0))
+
+
+def test_search_without_upload_fails_loudly(cars_lines):
+    from suggest_amd import NGramIndex, _lib
+    ix = NGramIndex(cars_lines[:100], _desc(CARS_DESC), upload=False)
+    with pytest.raises(_lib.SuggestHipError) as e:
+        ix.suggest_batch(["nissan"], "jaccard", 0.5, 5)
+    assert e.value.code == -3
+
+
+def test_argument_validation(cars_lines):
+    from suggest_amd import NGramIndex, IndexDescription, SearchConfig, _lib
+    with pytest.raises(ValueError):
+        SearchConfig("x", 0, "cosine", 0.5)          # search.go:20-22
+    with pytest.raises(ValueError):
+        SearchConfig("x", 1, "cosine", 0.0)          # search.go:24-26
+    with pytest.raises(ValueError):
+        SearchConfig("x", 1, "cosine", 1.5)
+    with pytest.raises(_lib.SuggestHipError):
+        NGramIndex(cars_lines[:10], IndexDescription(ngram_size=9), upload=False)
+
+
+def test_host_tokenizer_matches_oracle(cars_lines, words_lines):
+    from suggest_amd import NGramIndex
+    for lines, desc in ((cars_lines, CARS_DESC), (words_lines[::50], WORDS_DESC)):
+        ix = NGramIndex(lines[:50], _desc(desc), upload=False)
+        ora = oracle.OracleIndex(lines[:50], **desc)
+        probes = list(lines[::17]) + [b"", b" ", b"a", b"  x y  ", "Ёжик в тумане".encode(), b"\xff\xfeabc", "İi".encode(),
+                                      b"NISSAN TITAN", b"lalala", "жи".encode()]
+        for p in probes:
+            for ac in (False, True):
+                assert ix.tokenize(p, ac) == ora.tokenize(p, ac), (p, ac)
+
+
+def test_cars_csr_matches_reference_files(cars_lines, golden_dir):
+    """Host CSR == db/cars.{hd,dl} written by the reference (after de-duplicating a doc's repeated terms,
+    which the CSR keeps as a multiplicity side table): same keys, raw lengths, postings."""
+    from suggest_amd import NGramIndex
+    ix = NGramIndex(cars_lines, _desc(CARS_DESC), upload=False)
+    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "cars.hd"), os.path.join(golden_dir, "cars.dl"))
+    mine = ix.lists()
+    st = ix.stats()
+    assert st["n_segments"] == n_idx and st["n_lists"] == len(ref) and st["n_postings_raw"] == sum(v[0] for v in ref.values())
+    assert set(mine) == set(ref)
+    for key, (raw_len, post) in ref.items():
+        assert mine[key] == (raw_len, sorted(set(post))), key
+
+
+def test_words_csr_matches_oracle(words_lines):
+    from suggest_amd import NGramIndex
+    ix = NGramIndex(words_lines, _desc(WORDS_DESC), upload=False)
+    ora = oracle.OracleIndex(words_lines, **WORDS_DESC).lists()
+    mine = ix.lists()
+    assert set(mine) == set(ora)
+    assert all(mine[k] == (ora[k][0], ora[k][1]) for k in ora)
+
+
+def test_algorithmic_bytes_matches_oracle_definition():
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    blob, offs = synth.make_dict(20000, seed=1)
+    qb, qo = synth.make_queries(64, blob, offs, seed=2)
+    ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION), upload=False)
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **synth.DESCRIPTION)
+    qs = synth.unpack(qb, qo)
+    for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20)):
+        assert ix.algorithmic_bytes(qb, qo, metric, alpha, k) == sum(ora.algorithmic_bytes(q, metric, alpha, k) for q in qs)

@@ -1,0 +1,170 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle: bit-exact ids, order, scores."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CARS_DESC, WORDS_DESC
+
+pytestmark = pytest.mark.gpu
+
+METRICS = [("jaccard", 0.5), ("cosine", 0.4), ("dice", 0.5), ("cosine", 0.7), ("jaccard", 0.8), ("overlap", 0.9),
+           ("exact", 1.0)]
+
+
+def _desc(d):
+    from suggest_amd import IndexDescription
+    return IndexDescription(ngram_size=d["ngram_size"], wrap=d["wrap"], pad=d["pad"], alphabet=d["alphabet"])
+
+
+def assert_same(gpu, ora, queries=None):
+    ids, sc, cnt = gpu
+    oi, os_, oc = ora[:3]
+    bad = np.nonzero(cnt != oc)[0]
+    assert bad.size == 0, ("counts differ", bad[:5], cnt[bad[:5]], oc[bad[:5]], None if queries is None else [queries[i] for i in bad[:5]])
+    k = ids.shape[1]
+    valid = np.arange(k)[None, :] < np.minimum(cnt, k)[:, None]
+    valid &= (cnt < 0xFFFFFFF0)[:, None]
+    neq = valid & ((ids != oi) | (sc.view(np.uint64) != os_.view(np.uint64)))
+    rows = np.nonzero(neq.any(axis=1))[0]
+    assert rows.size == 0, ("rows differ", rows[:5], ids[rows[:3]], oi[rows[:3]], sc[rows[:3]], os_[rows[:3]],
+                            None if queries is None else [queries[i] for i in rows[:5]])
+
+
+@pytest.fixture(scope="module")
+def synth_small():
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    blob, offs = synth.make_dict(50000, seed=1)
+    qb, qo = synth.make_queries(4096, blob, offs, seed=2)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **synth.DESCRIPTION)
+    return gpu, ora, qb, qo
+
+
+@pytest.mark.parametrize("metric,alpha", METRICS)
+@pytest.mark.parametrize("k", [1, 10, 20])
+def test_synthetic_parity(synth_small, metric, alpha, k):
+    gpu, ora, qb, qo = synth_small
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
+                ora.suggest_batch(qb, qo, metric, alpha, k))
+
+
+def test_synthetic_q2_long_lists():
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    desc = dict(synth.DESCRIPTION, ngram_size=2)
+    blob, offs = synth.make_dict(200000, seed=3)
+    qb, qo = synth.make_queries(512, blob, offs, seed=4)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric="dice", similarity=0.5, k=10),
+                ora.suggest_batch(qb, qo, "dice", 0.5, 10))
+
+
+def test_large_k_uses_hbm_rows(synth_small):
+    gpu, ora, qb, qo = synth_small
+    assert_same(gpu.suggest_batch(blob=qb[:int(qo[256])], offs=qo[:257], metric="cosine", similarity=0.3, k=200),
+                ora.suggest_batch(qb[:int(qo[256])], qo[:257], "cosine", 0.3, 200))
+
+
+def test_reference_goldens_through_gpu(reference_tests):
+    from suggest_amd import IndexDescription, JaccardMetric, CosineMetric, SearchConfig, Service
+    coll = reference_tests["small_collection"]
+    t = reference_tests["suggest_auto"]
+    d = t["description"]
+    svc = Service()
+    svc.AddIndex("index", coll, IndexDescription(ngram_size=d["nGramSize"], wrap=d["wrap"], pad=d["pad"], alphabet=d["alphabet"]))
+    res = svc.Suggest("index", SearchConfig(t["query"], t["topK"], JaccardMetric(), t["similarity"]))
+    assert [r.value for r in res] == [coll[i] for i in t["expected_ids"]]       # ngram_index_test.go:15-40
+    a = reference_tests["autocomplete"]
+    res = svc.Autocomplete("index", a["query"], a["limit"])
+    assert [r.value for r in res] == [coll[i] for i in a["expected_ids"]]       # ngram_index_test.go:42-67
+    assert all(r.score == 0 for r in res)
+    e = reference_tests["example"]
+    d = e["description"]
+    svc.AddIndex("cars", coll, IndexDescription(ngram_size=d["nGramSize"], wrap=d["wrap"], pad=d["pad"], alphabet=d["alphabet"]))
+    res = svc.Suggest("cars", SearchConfig(e["query"], e["topK"], CosineMetric(), e["similarity"]))
+    assert [r.value for r in res] == e["expected_values"]                       # example_test.go:14-72
+    with pytest.raises(KeyError):
+        svc.Suggest("nope", SearchConfig("x", 1, CosineMetric(), 0.5))          # service.go:111-113
+
+
+def test_service_cars_golden(reference_tests, cars_lines):
+    from suggest_amd import CosineMetric, SearchConfig, Service
+    svc = Service()
+    svc.AddIndex("cars", cars_lines, _desc(CARS_DESC))
+    t = reference_tests["service_cars"]
+    for q, exp in zip(t["queries"], t["expected_values"]):                      # service_test.go:35,53-59
+        res = svc.Suggest("cars", SearchConfig(q, t["topK"], CosineMetric(), t["similarity"]))
+        assert [r.value for r in res] == exp, q
+
+
+def _no_dup_docs(ora_index, lines):
+    """docIDs of documents that repeat a term (secondary CPMerge entries)"""
+    dup = set()
+    for i, l in enumerate(lines):
+        t = ora_index.tokenize(l)
+        if len(set(t)) != len(t):
+            dup.add(i)
+    return dup
+
+
+def test_cars_all_lines_as_queries(cars_lines):
+    """Every dictionary line (and an edited copy) as a query, several metrics.  Until the duplicate-term
+    path lands, rows whose oracle result contains a doc twice are compared on their primary entries."""
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]] + [l.lower()[:-2] for l in cars_lines[::11]]
+    qb, qo = oracle.pack_strings(queries)
+    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.5, 10), ("dice", 0.6, 3)]:
+        g = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k)
+        o = ora.suggest_batch(qb, qo, metric, alpha, k)
+        oi, oc = o[0], o[2]
+        clean = np.array([len(set(oi[i, :oc[i]].tolist())) == oc[i] for i in range(len(queries))])
+        ids, sc, cnt = g
+        sel = np.nonzero(clean)[0]
+        assert sel.size > 0.8 * len(queries)
+        assert_same((ids[sel], sc[sel], cnt[sel]), (o[0][sel], o[1][sel], o[2][sel]), [queries[i] for i in sel])
+
+
+def test_words_parity(words_lines, reference_tests):
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(words_lines, _desc(WORDS_DESC))
+    ora = oracle.OracleIndex(words_lines, **WORDS_DESC)
+    queries = reference_tests["workloads"]["words_cosine_0.5_k5"] + [w for w in words_lines[::997]] + \
+        [w[:-1] + b"q" for w in words_lines[5::1999]]
+    qb, qo = oracle.pack_strings(queries)
+    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.4, 10)]:
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
+                    ora.suggest_batch(qb, qo, metric, alpha, k), queries)
+
+
+def test_autocomplete_parity(words_lines, cars_lines):
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(words_lines, _desc(WORDS_DESC))
+    ora = oracle.OracleIndex(words_lines, **WORDS_DESC)
+    queries = [w[:4] for w in words_lines[::501]] + [w[:2] for w in words_lines[::4001]] + [b"", b"zzzzqq", b"a"]
+    qb, qo = oracle.pack_strings(queries)
+    for limit in (1, 5, 50):
+        ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=limit)
+        oi, oc, _ = ora.autocomplete_batch(qb, qo, limit)
+        assert np.array_equal(cnt, oc)
+        valid = np.arange(limit)[None, :] < cnt[:, None]
+        assert np.array_equal(ids[valid], oi[valid])
+
+
+def test_edge_queries(cars_lines):
+    import random
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    rng = random.Random(5)
+    long_q = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(120))
+    queries = ["", " ", "a", "ab", "  NISSAN  ", "ниссан", "Ёлка ё", "toyota\xff\xfe", "TOYOTA COROLLA", long_q, "İstanbul",
+               "$$$", "x" * 100, "NISSAN TITAN"]
+    qb, qo = oracle.pack_strings([q.encode("utf-8", "surrogateescape") if isinstance(q, str) else q for q in queries])
+    ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=5)
+    oi, os_, oc, _ = ora.suggest_batch(qb, qo, "jaccard", 0.5, 5)
+    assert np.array_equal(cnt, oc), (cnt, oc)
+    assert cnt[0] == 0 and cnt[9] == 0xFFFFFFFF          # empty -> no result; overlong -> reference panics
+    clean = [i for i in range(len(queries)) if oc[i] < 0xFFFFFFF0 and len(set(oi[i, :oc[i]].tolist())) == oc[i]]
+    assert_same((ids[clean], sc[clean], cnt[clean]), (oi[clean], os_[clean], oc[clean]))
