@@ -738,9 +738,44 @@ or_index* or_index_build(const uint8_t* blob, const uint64_t* offs, uint32_t n_d
   auto* h = new or_index();
   h->ix.d.q = q; h->ix.d.wrap0 = wrap0; h->ix.d.wrap1 = wrap1; h->ix.d.pad = pad;
   h->ix.d.alphabet = Alphabet::create(split_alphabet(alphabet_nl));
-  for (uint32_t i = 0; i < n_docs; i++) {
-    std::string s((const char*)blob + offs[i], (size_t)(offs[i + 1] - offs[i]));
-    add_document(h->ix, i, tokenize(h->ix.d, s, false));
+  // Documents are added in docID order (suggest.Index, indexer.go:32-34).  For large dictionaries the
+  // work is split into contiguous docID ranges built in parallel and concatenated in range order,
+  // which yields exactly the lists a sequential AddDocument loop produces.
+  int n_chunks = 1;
+#ifdef _OPENMP
+  if (n_docs >= 200000) n_chunks = std::min(32, omp_get_max_threads());
+#endif
+  if (n_chunks <= 1) {
+    for (uint32_t i = 0; i < n_docs; i++) {
+      std::string s((const char*)blob + offs[i], (size_t)(offs[i + 1] - offs[i]));
+      add_document(h->ix, i, tokenize(h->ix.d, s, false));
+    }
+  } else {
+    std::vector<Index> parts(n_chunks);
+#pragma omp parallel for schedule(static, 1) num_threads(n_chunks)
+    for (int c = 0; c < n_chunks; c++) {
+      parts[c].d = h->ix.d;
+      uint64_t lo = (uint64_t)n_docs * c / n_chunks, hi = (uint64_t)n_docs * (c + 1) / n_chunks;
+      for (uint64_t i = lo; i < hi; i++) {
+        std::string s((const char*)blob + offs[i], (size_t)(offs[i + 1] - offs[i]));
+        add_document(parts[c], (uint32_t)i, tokenize(h->ix.d, s, false));
+      }
+    }
+    size_t n_seg = 0;
+    for (auto& p : parts) n_seg = std::max(n_seg, p.segs.size());
+    h->ix.segs.resize(n_seg);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_chunks)
+    for (int64_t sg = 0; sg < (int64_t)n_seg; sg++) {
+      for (auto& p : parts) {
+        if ((size_t)sg >= p.segs.size() || !p.segs[sg]) continue;
+        if (!h->ix.segs[sg]) h->ix.segs[sg] = std::make_unique<Segment>();
+        for (auto& kv : p.segs[sg]->terms) {
+          auto& dst = h->ix.segs[sg]->terms[kv.first].v;
+          dst.insert(dst.end(), kv.second.v.begin(), kv.second.v.end());
+        }
+        p.segs[sg].reset();
+      }
+    }
   }
   commit(h->ix);
   return h;

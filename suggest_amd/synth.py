@@ -2,7 +2,8 @@
 
 Counter-based splitmix64: draw(seed, i, j) = mix(seed * 0x9E3779B97F4A7C15 + i * 64 + j), so the
 generator vectorises and any slice of the dictionary can be produced independently.
-  dict(N, seed=1):   doc i has length 8 + draw(seed,i,0) % 25 over [a-z0-9] (chars draw(seed,i,1+j) % 36)
+  dict(N, seed=1):   doc i has length 8 + draw(seed,i,0) % 25 over [a-z0-9]; char c of doc i is
+                     alphabet[byte (c%8) of draw(seed,i,1+c//8) % 36]
   queries(M, seed=2): query q = doc draw(seed,q,0) % N with 1 + draw(seed,q,1) % 2 random edits
                       (substitute / delete / insert at a random position, random symbol)
 Normalisation is the identity on this alphabet, so no document repeats a term.
@@ -39,8 +40,9 @@ def make_dict(n, seed=1, chunk=1 << 20):
         idx = np.arange(s, e, dtype=np.uint64)
         L = 8 + (draw(seed, idx, 0) % np.uint64(25)).astype(np.int64)
         lens[s:e] = L
-        j = np.arange(32, dtype=np.uint64)
-        ch = ALPHABET[(draw(seed, idx[:, None], j[None, :] + np.uint64(1)) % np.uint64(36)).astype(np.int64)]
+        j = np.arange(4, dtype=np.uint64)
+        words = draw(seed, idx[:, None], j[None, :] + np.uint64(1))          # [n,4] u64 -> 32 bytes per doc
+        ch = ALPHABET[np.ascontiguousarray(words).view(np.uint8).reshape(e - s, 32) % np.uint8(36)]
         mask = np.arange(32)[None, :] < L[:, None]
         parts.append(ch[mask])
     offs = np.zeros(n + 1, dtype=np.uint64)
