@@ -28,6 +28,10 @@ namespace sg {
 #define SG_CAND_CAP 64
 #define SG_K_LDS 64
 #define SG_WRAP_MAX 8
+#define SG_ROWS_CAP 1024   // u32 entries of seg_off rows kept in LDS per tile
+#define SG_TILE_MAX 64     // segments per tile (one lane each)
+#define SG_UNROLL 4        // 16-byte loads in flight per lane
+#define SG_ADDR_CAP 1024   // chunk-directory entries per streaming window
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -59,7 +63,9 @@ struct BatchArgs {
   double alpha;
   uint32_t n_q, k;
   int metric, autocomplete;
-  uint32_t log2_nb;     // u16 buckets per wave = 1 << log2_nb
+  uint32_t log2_cnt;    // LDS counter words per wave = 1 << log2_cnt
+  unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
+  uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -277,13 +283,16 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
   return (int)n_tok;
 }
 
-// inclusive wave scan (64 lanes)
+// inclusive wave scan (64 lanes) on the DPP network: Hillis-Steele inside rows of 16 lanes
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals — no LDS traffic.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+  (void)lane;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
   return v;
 }
 
@@ -325,21 +334,99 @@ __device__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
   topk_recompute_worst(tk, lane);
 }
 
+// Buckets a group of `postings` postings needs so that a bucket reaching T by chance is rare
+// (expected false buckets per group ~<= 0.1): postings / lambda(T).
+__device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T) {
+  // 16/lambda(T) with lambda = 4, 3.2, 2, 1.23, 0.5, 0.31, 0.125 postings per bucket
+  const uint32_t m16 = T >= 14 ? 4u : T >= 12 ? 5u : T >= 10 ? 8u : T >= 8 ? 13u : T >= 6 ? 32u : T == 5 ? 51u : 128u;
+  return (postings * m16) >> 4;
+}
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+static_assert(SG_UNROLL == 4, "u32x16 below holds 4 chunks x 4 postings");
+
+// One streaming step over up to 64*SG_UNROLL chunks whose data is already in v[]: one LDS atomic
+// per posting (U8: four u8 counters per word, else one u32 counter per word), issued back to back.
+// Returns the ballot of lanes holding a posting whose bucket reached T; `was` receives the bucket
+// counts seen (for the rare slow path).  TAIL masks lanes past the end of the stream (they re-read
+// the last chunk).
+template <bool U8, bool TAIL>
+__device__ __forceinline__ uint64_t count_step(const uint4 (&v)[SG_UNROLL], uint32_t* cnt, uint32_t c0, uint32_t L,
+                                               uint32_t bmask, uint32_t Tm1, int lane, u32x16& was) {
+  uint32_t old[4 * SG_UNROLL];
+  uint32_t shf[U8 ? 4 * SG_UNROLL : 1];
+#pragma unroll
+  for (int u = 0; u < SG_UNROLL; u++) {
+    const uint32_t live = (!TAIL || c0 + u * 64 + lane < L) ? 1u : 0u;
+    const uint32_t dv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t b = dv[e] & bmask;
+      if (U8) {
+        const uint32_t sh = (b & 3u) << 3;
+        shf[u * 4 + e] = sh;
+        old[u * 4 + e] = atomicAdd(&cnt[b >> 2], live << sh);
+      } else {
+        old[u * 4 + e] = atomicAdd(&cnt[b], live);
+      }
+    }
+  }
+  uint32_t mx = 0;
+#pragma unroll
+  for (int u = 0; u < SG_UNROLL; u++) {
+    const bool live = !TAIL || c0 + u * 64 + lane < L;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      uint32_t o = old[u * 4 + e];
+      if (U8) o = (o >> shf[u * 4 + e]) & 0xFFu;
+      if (TAIL) o = live ? o : 0u;
+      was[u * 4 + e] = o;
+      mx = max(mx, o);
+    }
+  }
+  return ballot(mx >= Tm1);
+}
+
 // ------------------------------------------------------------------------------------------
 // The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
-//   cnt[(1<<log2_nb)/2] u32  (tokeniser scratch aliases it) | term | lstart | lprefix | cand | topk
+//   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | lstart | lprefix | rows | addr | cand | topk
+//
+// Per query: the admissible window of cardinality segments is cut into tiles; for a tile the
+// chunk offsets seg_off[term][b] of every query term are fetched once into LDS (`rows`), lane w
+// then owns segment w of the tile (its threshold T, posting volume, number of present terms).
+// Consecutive valid segments are merged into groups (term-major CSR keeps a term's postings for
+// consecutive segments contiguous) and each group is streamed once:
+//   chunk directory addr[] built in LDS (one entry per 16-byte chunk)  ->  16-byte coalesced loads,
+//   SG_UNROLL in flight per lane and the next step's loads issued before the current step is
+//   counted  ->  one LDS atomic per posting  ->  postings whose bucket reaches T are verified
+//   exactly (binary searches in the term lists of the doc's own segment), scored and offered to
+//   the wave's top-k.
 // ------------------------------------------------------------------------------------------
+#ifdef SG_PHASE_TIMING   // tools/phase_timing.py: where do a wavefront's cycles go (s_memtime brackets)
+#define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_last = clock64();
+#define PH(n) { const long long ph_now = clock64(); ph_acc[n] += ph_now - ph_last; ph_last = ph_now; }
+#define PH_FLUSH if (lane < 8 && a.prof) { atomicAdd(a.prof + (qi & 4095u) * 8 + lane, (unsigned long long)ph_acc[lane]); }
+#define DBG_SKIP(bit) (a.dbg_skip & (bit))
+#else
+#define DBG_SKIP(bit) false
+#define PH_DECL
+#define PH(n)
+#define PH_FLUSH
+#endif
+
 __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
   const uint32_t qi = blockIdx.x;
   const DeviceIndex& ix = a.ix;
-  const uint32_t cnt_words = (1u << a.log2_nb) >> 1;
+  const uint32_t cnt_words = 1u << a.log2_cnt;
   uint32_t* cnt = smem;
   uint32_t* term = cnt + cnt_words;
   uint32_t* lstart = term + SG_MAX_A;
   uint32_t* lprefix = lstart + SG_MAX_A;           // SG_MAX_A + 1 (+3 pad)
-  uint32_t* cand = lprefix + SG_MAX_A + 4;
+  uint32_t* rows = lprefix + SG_MAX_A + 4;
+  uint32_t* addr = rows + SG_ROWS_CAP;
+  uint32_t* cand = addr + SG_ADDR_CAP;
   uint32_t* tk_id_lds = cand + SG_CAND_CAP;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
@@ -351,7 +438,11 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
+  PH_DECL
+  if (DBG_SKIP(32u)) { if (lane == 0) a.out_counts[qi] = 0; return; }
   const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
+  PH(0)
+  if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; return; }
   if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; return; }
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
 
@@ -373,157 +464,270 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   tk.id = tk_in_lds ? tk_id_lds : a.scratch_id + (uint64_t)qi * k;
   tk.n = 0; tk.k = k; tk.worst_s = 0; tk.worst_id = 0; tk.worst_pos = 0;
 
-  const uint4* post4 = (const uint4*)ix.postings;
-  const int a_rounds = (A + 63) >> 6;
+  const uint4* __restrict__ post4 = (const uint4*)ix.postings;
+  const int a_rounds = (A + 63) >> 6;                          // 1 or 2 (A <= SG_MAX_A = 128)
+  const int wt_max = min(SG_TILE_MAX, SG_ROWS_CAP / A - 1);   // A <= 128 -> >= 7
+  const uint32_t max_buckets = cnt_words * 4u;                 // u8 mode
 
-  for (int B = max(b_min, 0); B <= b_max; B++) {
-    int T;
-    if (a.autocomplete) T = A;
-    else {
-      T = d_threshold(a.metric, a.alpha, A, B);
-      if (T == 0 || T > B || T > A) continue;              // suggester.go:76
-    }
-    // ---- posting ranges of the query terms in segment B (searcher.go:38-58) ----
+  for (int tb = max(b_min, 0); tb <= b_max; tb += wt_max) {
+    const int Wt = min(wt_max, b_max - tb + 1);
+    const uint32_t stride = (uint32_t)Wt + 1;
+    // ---- chunk offsets of every query term for segments tb .. tb+Wt (searcher.go:38-58) ----
     __syncthreads();
-    uint32_t running = 0, nonempty = 0;
-    for (int r = 0; r < a_rounds; r++) {
-      const int i = r * 64 + lane;
-      uint32_t s = 0, len = 0;
-      if (i < A) {
-        const uint32_t t = term[i];
-        if (t != kNoTerm) {
-          const uint32_t* so = ix.seg_off + (uint64_t)t * (uint32_t)(S + 1) + (uint32_t)B;
-          s = so[0]; len = so[1] - s;
-        }
-      }
-      const uint32_t incl = wave_scan_incl(len, lane);
-      if (i < A) { lstart[i] = s; lprefix[i] = running + incl - len; }
-      running += readlane(incl, 63);
-      nonempty += popc64(ballot(len != 0));
+    for (uint32_t e = lane; e < (uint32_t)A * stride; e += 64) {
+      const uint32_t i = e / stride, w = e - i * stride;
+      const uint32_t t = term[i];
+      rows[e] = t == kNoTerm ? 0u : ix.seg_off[(uint64_t)t * (uint32_t)(S + 1) + (uint32_t)tb + w];
     }
-    if (lane == 0) lprefix[A] = running;
-    if ((int)nonempty < T) continue;                        // fewer present terms than T: searcher.go:32
-    const uint32_t L = running;                             // 16-byte chunks to stream
-    // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
-    const bool wide = L >= 16383u;                          // >= 65532 postings: 32-bit counters
-    uint32_t want = L * 8u;                                 // ~2 buckets per posting
-    if (T < 10) want <<= 2;
-    if (T < 6) want <<= 2;
-    uint32_t lg = 8;
-    const uint32_t lg_max = wide ? a.log2_nb - 1 : a.log2_nb;
-    while (lg < lg_max && (1u << lg) < want) lg++;
-    const uint32_t words = wide ? (1u << lg) : (1u << lg) >> 1;
-    for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
-    uint32_t ncand = 0;
-    bool overflow = false;
     __syncthreads();
-
-    // wave-cooperative exact overlap of doc d in segment B: sum over query-term occurrences
-    auto verify = [&](uint32_t d, int* last_list) -> int {
-      int c = 0, last = -1;
-      for (int r = 0; r < a_rounds; r++) {
-        const int i = r * 64 + lane;
-        bool found = false;
-        if (i < A) {
-          const uint32_t nch = lprefix[i + 1] - lprefix[i];
-          if (nch) {
-            const uint32_t* p = ix.postings + (uint64_t)lstart[i] * 4;
-            uint32_t lo = 0, hi = nch * 4;
-            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
-            found = lo < nch * 4 && p[lo] == d;
-          }
-        }
-        const uint64_t m = ballot(found);
-        c += (int)popc64(m);
-        if (m) last = r * 64 + 63 - __builtin_clzll(m);
+    // ---- lane w owns segment tb+w: posting volume, present terms, threshold ----
+    uint32_t seg_tot = 0;
+    int seg_T = 0;
+    bool seg_valid = false;
+    if (lane < Wt) {
+      uint32_t ne = 0;
+      for (int i = 0; i < A; i++) {
+        const uint32_t len = rows[i * stride + lane + 1] - rows[i * stride + lane];
+        seg_tot += len; ne += len != 0;
       }
-      *last_list = last;
-      return c;
-    };
-    auto emit = [&](uint32_t d, int overlap) {
-      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
-      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, B)), d, lane);
-    };
-
-    // ---- single streaming pass: count, flag buckets reaching T, verify flagged docs once ----
-    for (uint32_t c0 = 0; c0 < L; c0 += 64) {
-      const uint32_t c = c0 + lane;
-      const bool act = c < L;
-      uint4 v = make_uint4(kPadDoc, kPadDoc, kPadDoc, kPadDoc);
-      if (act) {
-        uint32_t lo = 0, hi = (uint32_t)A;                  // last list j with lprefix[j] <= c
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= c) lo = mid; else hi = mid; }
-        v = post4[lstart[lo] + (c - lprefix[lo])];
+      const int B = tb + lane;
+      if (a.autocomplete) { seg_T = A; seg_valid = true; }
+      else {
+        seg_T = d_threshold(a.metric, a.alpha, A, B);
+        seg_valid = !(seg_T == 0 || seg_T > B || seg_T > A);       // suggester.go:76
       }
-      const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const uint32_t d = dv[e];
-        bool flag = false;
-        if (d != kPadDoc) {
-          const uint32_t b = (d * 2654435761u) >> (32 - lg);
-          uint32_t now;
-          if (wide) now = atomicAdd(&cnt[b], 1u) + 1;
-          else {
-            const uint32_t sh = (b & 1u) * 16u;
-            now = ((atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xFFFFu) + 1;
-          }
-          flag = now >= (uint32_t)T;
-        }
-        uint64_t m = ballot(flag);
-        while (m) {                                         // rare; wave-uniform
-          const int l = __builtin_ctzll(m);
-          m &= m - 1;
-          const uint32_t dd = readlane(d, l);
-          bool seen = false;
-          for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
-          if (ballot(seen)) continue;
-          if (ncand == SG_CAND_CAP) { overflow = true; continue; }
-          if (lane == 0) cand[ncand] = dd;
-          ncand++;
-          __syncthreads();
-          int last;
-          const int ov = verify(dd, &last);
-          if (ov >= T) emit(dd, ov);
-        }
-      }
+      seg_valid = seg_valid && (int)ne >= seg_T;                     // searcher.go:32 (fewer present terms than T)
     }
-    if (overflow) {
-      // More distinct candidates than the dedup set holds: second pass over the final counters;
-      // every doc is handled exactly once, at its occurrence in the last list that contains it.
+    const uint64_t vmask = ballot(seg_valid);
+    PH(1)
+
+    int wnext = DBG_SKIP(16u) ? Wt : 0;
+    while (wnext < Wt) {
+      const uint64_t rest = (vmask >> wnext) << wnext;
+      if (!rest) break;
+      const int g0 = __builtin_ctzll(rest);
+      int g1 = g0;
+      uint32_t L_est = readlane(seg_tot, g0);
+      int Tmin = (int)readlane((uint32_t)seg_T, g0);
+      // merge following valid segments while the counters still resolve the group and its chunk
+      // directory fits in LDS
+      for (;;) {
+        const int nx = g1 + 1;
+        if (nx >= Wt || !((vmask >> nx) & 1)) break;
+        const uint32_t nt = readlane(seg_tot, nx);
+        const int tm = min(Tmin, (int)readlane((uint32_t)seg_T, nx));
+        if (L_est + nt > SG_ADDR_CAP || buckets_needed((L_est + nt) * 4u, tm) > max_buckets) break;
+        L_est += nt; Tmin = tm; g1 = nx;
+      }
+      wnext = g1 + 1;
+
+      // ---- the group's lists: list i = postings of term i over segments tb+g0 .. tb+g1 ----
       __syncthreads();
-      for (uint32_t c0 = 0; c0 < L; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        const bool act = c < L;
-        uint4 v = make_uint4(kPadDoc, kPadDoc, kPadDoc, kPadDoc);
-        uint32_t lo = 0;
-        if (act) {
-          uint32_t hi = (uint32_t)A;
-          while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= c) lo = mid; else hi = mid; }
-          v = post4[lstart[lo] + (c - lprefix[lo])];
-        }
-        const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
+      uint32_t running = 0;
+      uint32_t ls_r[2] = {0, 0}, ln_r[2] = {0, 0}, pb_r[2] = {0, 0};   // this lane's list (per round): start, chunks, prefix
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const uint32_t d = dv[e];
-          bool flag = false;
-          if (d != kPadDoc) {
-            const uint32_t b = (d * 2654435761u) >> (32 - lg);
-            const uint32_t now = wide ? cnt[b] : ((cnt[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu);
-            flag = now >= (uint32_t)T;
+      for (int r = 0; r < 2; r++) {
+        if (r < a_rounds) {
+          const int i = r * 64 + lane;
+          uint32_t s = 0, len = 0;
+          if (i < A) { s = rows[i * stride + g0]; len = rows[i * stride + g1 + 1] - s; }
+          const uint32_t incl = wave_scan_incl(len, lane);
+          ls_r[r] = s; ln_r[r] = len; pb_r[r] = running + incl - len;
+          if (i < A) { lstart[i] = s; lprefix[i] = pb_r[r]; }
+          running += readlane(incl, 63);
+        }
+      }
+      if (lane == 0) lprefix[A] = running;
+      const uint32_t L = running;                             // 16-byte chunks to stream
+      // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
+      // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
+      // word; a u8 counter that saturates (needs > 255 postings in one bucket) re-runs the group wide.
+      const uint32_t need = buckets_needed(L * 4u, Tmin);
+      bool u8 = need > cnt_words && Tmin <= 200;
+      uint32_t lg = 8;
+      {
+        const uint32_t lg_max = u8 ? a.log2_cnt + 2 : a.log2_cnt;
+        while (lg < lg_max && (1u << lg) < need) lg++;
+      }
+      uint32_t ncand = 0;
+      bool overflow = false;
+
+      // exact overlap of doc d (found in list jj at chunk cc): locate its segment, then count the
+      // query-term occurrences whose list in that segment contains d (wave-cooperative)
+      auto verify = [&](uint32_t d, uint32_t jj, uint32_t cc, int* seg_w, int* last_list) -> int {
+        const uint32_t abs = lstart[jj] + (cc - lprefix[jj]);
+        int w = g0;
+        while (w < g1 && rows[jj * stride + w + 1] <= abs) w++;
+        *seg_w = w;
+        int c = 0, last = -1;
+        for (int r = 0; r < a_rounds; r++) {
+          const int i = r * 64 + lane;
+          bool found = false;
+          if (i < A) {
+            const uint32_t s0 = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0;
+            if (nch) {
+              const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
+              uint32_t lo = 0, hi = nch * 4;
+              while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
+              found = lo < nch * 4 && p[lo] == d;
+            }
           }
-          uint64_t m = ballot(flag);
-          while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t dd = readlane(d, l);
-            const int jj = (int)readlane(lo, l);
-            bool seen = false;
-            for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
-            if (ballot(seen)) continue;
-            int last;
-            const int ov = verify(dd, &last);
-            if (last == jj && ov >= T) emit(dd, ov);
+          const uint64_t m = ballot(found);
+          c += (int)popc64(m);
+          if (m) last = r * 64 + 63 - __builtin_clzll(m);
+        }
+        *last_list = last;
+        return c;
+      };
+      auto emit = [&](uint32_t d, int overlap, int w) {
+        const int T = (int)readlane((uint32_t)seg_T, w);
+        if (overlap < T) return;
+        if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);       // score = -docID, collector.go:104-106
+        else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
+      };
+      auto in_cand = [&](uint32_t dd) -> bool {
+        bool seen = false;
+        for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
+        return ballot(seen) != 0;
+      };
+      auto locate = [&](uint32_t cc) -> uint32_t {            // list holding chunk cc (uniform)
+        uint32_t lo = 0, hi = (uint32_t)A;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= cc) lo = mid; else hi = mid; }
+        return lo;
+      };
+      bool saturated = false;
+      auto on_flag = [&](uint32_t dd, uint32_t cc) {          // dd was flagged at stream position (chunk) cc
+        if (u8) {                                              // a saturating u8 counter would carry into its neighbour
+          const uint32_t b = dd & ((1u << lg) - 1u);
+          if (((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) >= 250u) saturated = true;
+        }
+        if (in_cand(dd)) return;
+        if (ncand == SG_CAND_CAP) { overflow = true; return; }
+        if (lane == 0) cand[ncand] = dd;
+        ncand++;
+        __syncthreads();
+        int w, last;
+        const int ov = verify(dd, locate(cc), cc, &w, &last);
+        emit(dd, ov, w);
+      };
+
+      // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
+      PH(2)
+      for (int attempt = 0; attempt < 2; attempt++) {
+        const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
+        if (!DBG_SKIP(1u))
+        for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
+        const uint32_t bmask = (1u << lg) - 1u, Tm1 = (uint32_t)Tmin - 1u;
+        for (uint32_t w0 = 0; w0 < L; w0 += SG_ADDR_CAP) {    // windows of the chunk directory
+          const uint32_t Lw = min((uint32_t)SG_ADDR_CAP, L - w0);
+          __syncthreads();
+          PH(3)
+          // chunk directory: addr[c - w0] = global chunk index of stream position c
+          if (DBG_SKIP(2u)) {
+          } else if (L >= 16u * (uint32_t)A) {                  // long lists: the wave walks each list
+            const bool one_window = L <= SG_ADDR_CAP;
+            for (int i = 0; i < A; i++) {
+              const int r = i >> 6, li = i & 63;
+              const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li),
+                             pb = readlane(r ? pb_r[1] : pb_r[0], li);
+              if (one_window) {
+                if ((uint32_t)lane < n) addr[pb + lane] = s + lane;
+                if (n > 64) for (uint32_t kk = 64 + lane; kk < n; kk += 64) addr[pb + kk] = s + kk;
+              } else {
+                if (pb + n <= w0 || pb >= w0 + Lw) continue;
+                const uint32_t k0 = pb < w0 ? w0 - pb : 0u, k1 = min(n, w0 + Lw - pb);
+                for (uint32_t kk = k0 + lane; kk < k1; kk += 64) addr[pb + kk - w0] = s + kk;
+              }
+            }
+          } else {                                              // short lists: one lane per list
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              if (r < a_rounds) {
+                const uint32_t s = ls_r[r], n = ln_r[r], pb = pb_r[r];
+                const uint32_t k0 = pb < w0 ? min(n, w0 - pb) : 0u, k1 = pb >= w0 + Lw ? 0u : min(n, w0 + Lw - pb);
+                for (uint32_t kk = k0; kk < k1; kk++) addr[pb + kk - w0] = s + kk;
+              }
+            }
+          }
+          __syncthreads();
+          PH(4)
+          // stream the window: loads of step i+1 are issued before step i is counted
+          uint4 v[SG_UNROLL], vn[SG_UNROLL];
+          u32x16 was;
+#pragma unroll
+          for (int u = 0; u < SG_UNROLL; u++) v[u] = post4[addr[min((uint32_t)(u * 64 + lane), Lw - 1)]];
+          for (uint32_t c0 = 0; c0 < Lw; c0 += 64 * SG_UNROLL) {
+            const bool more = c0 + 64 * SG_UNROLL < Lw;
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < SG_UNROLL; u++) vn[u] = post4[addr[min(c0 + 64 * SG_UNROLL + u * 64 + lane, Lw - 1)]];
+            }
+            const bool tail = c0 + 64 * SG_UNROLL > Lw;
+            uint64_t any;
+            if (DBG_SKIP(4u)) { any = 0; asm volatile("" :: "v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x)); }
+            else if (u8) any = tail ? count_step<true, true>(v, cnt, c0, Lw, bmask, Tm1, lane, was) : count_step<true, false>(v, cnt, c0, Lw, bmask, Tm1, lane, was);
+            else any = tail ? count_step<false, true>(v, cnt, c0, Lw, bmask, Tm1, lane, was) : count_step<false, false>(v, cnt, c0, Lw, bmask, Tm1, lane, was);
+            if (any) {                                          // rare; wave-uniform
+              PH(5)
+              const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                                 v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma nounroll
+              for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {      // uniform dynamic index into the register vectors
+                uint64_t m = ballot(was[ue] >= Tm1);
+                const uint32_t dsel = vv[ue];
+                while (m) {
+                  const int l = __builtin_ctzll(m);
+                  m &= m - 1;
+                  on_flag(readlane(dsel, l), w0 + c0 + (uint32_t)(ue >> 2) * 64 + (uint32_t)l);
+                }
+              }
+              PH(6)
+            }
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < SG_UNROLL; u++) v[u] = vn[u];
+            }
+          }
+        }
+        PH(5)
+        if (!(u8 && saturated)) break;
+        // re-run with u32 counters: candidates already verified stay in the dedup set (emitted once)
+        u8 = false; saturated = false;
+        lg = min(lg, a.log2_cnt);
+        __syncthreads();
+      }
+
+      if (overflow) {
+        // More distinct candidates than the dedup set holds: second pass over the final counters;
+        // every remaining doc is handled exactly once, at its occurrence in the last list holding it
+        // (padding repeats a list's last doc inside its last chunk: skipped as equal neighbours).
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < L; c0 += 64) {
+          const uint32_t c = c0 + lane;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          uint32_t lo = 0;
+          if (c < L) { lo = locate(c); v = post4[lstart[lo] + (c - lprefix[lo])]; }
+          const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const uint32_t d = dv[e];
+            bool flag = false;
+            if (c < L && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
+              const uint32_t b = d & ((1u << lg) - 1u);
+              const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[b];
+              flag = now >= (uint32_t)Tmin;
+            }
+            uint64_t m = ballot(flag);
+            while (m) {
+              const int l = __builtin_ctzll(m);
+              m &= m - 1;
+              const uint32_t dd = readlane(d, l);
+              const uint32_t jj = readlane(lo, l);
+              if (in_cand(dd)) continue;
+              int w, last;
+              const int ov = verify(dd, jj, c0 + l, &w, &last);
+              if (last == (int)jj) emit(dd, ov, w);
+            }
           }
         }
       }
@@ -546,6 +750,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
+  PH(7)
+  PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------
@@ -566,7 +772,7 @@ struct sg_index {
   DeviceIndex dix{};
   std::vector<void*> allocs;
   uint64_t device_bytes = 0;
-  uint32_t log2_nb = 12;
+  uint32_t log2_cnt = 10;
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -577,6 +783,8 @@ struct sg_index {
       return SG_E_HIP;                                                                  \
     }                                                                                   \
   } while (0)
+
+static void* g_prof_buf = nullptr;   // SG_PHASE_TIMING builds only (sg_debug_set_prof)
 
 namespace {
 
@@ -597,8 +805,8 @@ const LowerPair kLowerPairs[] = {
 #include "unicode_lower.inc"
 };
 
-size_t lds_bytes(uint32_t log2_nb) {
-  size_t words = ((1u << log2_nb) >> 1) + SG_MAX_A * 3 + 4 + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
+size_t lds_bytes(uint32_t log2_cnt) {
+  size_t words = (1u << log2_cnt) + SG_MAX_A * 3 + 4 + SG_ROWS_CAP + SG_ADDR_CAP + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
@@ -629,14 +837,18 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
   a.k = k;
   a.metric = metric;
   a.autocomplete = autocomplete;
-  a.log2_nb = index->log2_nb;
+  a.log2_cnt = index->log2_cnt;
+  a.prof = (unsigned long long*)g_prof_buf;
+#ifdef SG_PHASE_TIMING
+  { const char* e = getenv("SG_DEBUG_SKIP"); a.dbg_skip = e ? (uint32_t)atoi(e) : 0u; }
+#endif
   void* scratch = nullptr;
   if (k > SG_K_LDS) {  // top-k working rows in HBM (stream-ordered allocation)
     HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
     a.scratch_s = (uint64_t*)scratch;
     a.scratch_id = (uint32_t*)((char*)scratch + (size_t)n_q * k * 8);
   }
-  hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_nb), stream, a);
+  hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
   HIP_TRY(hipGetLastError());
   if (scratch) HIP_TRY(hipFreeAsync(scratch, stream));
   return SG_OK;
@@ -697,10 +909,10 @@ int sg_index_upload(sg_index* ix, int device) {
   d.n_pad = h.sym.n_pad;
   memcpy(d.pad_sym, h.sym.pad_sym, 8);
   ix->device = device;
-  const char* env = getenv("SG_LOG2_NB");
-  if (env) { int v = atoi(env); if (v >= 10 && v <= 15) ix->log2_nb = (uint32_t)v; }
+  const char* env = getenv("SG_LOG2_CNT");   // tuning knob: LDS counter words per wavefront (default 1024)
+  if (env) { int v = atoi(env); if (v >= 9 && v <= 14) ix->log2_cnt = (uint32_t)v; }
   HIP_TRY(hipFuncSetAttribute((const void*)sg_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes(15)));
+                              (int)lds_bytes(14)));
   ix->uploaded = true;
   return SG_OK;
 }
@@ -774,6 +986,10 @@ int sg_autocomplete_batch(sg_index* index, const uint8_t* q, const uint64_t* off
   if (!offs || !ids || !counts) { set_error("null argument"); return SG_E_INVALID; }
   return run_host(index, q, offs, n_q, 0, 0, limit, 1, ids, nullptr, counts);
 }
+
+#ifdef SG_PHASE_TIMING
+void sg_debug_set_prof(void* device_u64x8) { g_prof_buf = device_u64x8; }
+#endif
 
 int sg_index_stats(const sg_index* ix, sg_stats* out) {
   if (!ix || !out) { set_error("null argument"); return SG_E_INVALID; }

@@ -308,7 +308,7 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
     ix.seg_off[t * (S + 1) + S] = (uint32_t)chunk;
     if (chunk >= 0xFFFFFFF0ull) { err = "posting store exceeds 2^32 16-byte chunks"; return SG_E_UNSUPPORTED; }
   }
-  ix.postings.assign((size_t)chunk * 4, kPadDoc);
+  ix.postings.assign((size_t)chunk * 4, 0);
   std::vector<uint32_t> cursor(nT * (size_t)S, 0);
   for (uint32_t d = 0; d < n_docs; d++) {           // ascending docID => every list ascending
     uint32_t b = doc_card[d];
@@ -317,6 +317,15 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
       ix.postings[(size_t)ix.seg_off[t * (S + 1) + b] * 4 + cursor[t * S + b]++] = d;
     }
   }
+  // pad every list to a whole 16-byte chunk by repeating its last docID: the kernel's lossy counters
+  // stay upper bounds and its binary searches stay valid without a per-posting sentinel test
+  for (size_t t = 0; t < nT; t++)
+    for (uint32_t b = 0; b < S; b++) {
+      const uint32_t len = ix.list_len[t * S + b];
+      if (!len || !(len & 3)) continue;
+      uint32_t* p = ix.postings.data() + (size_t)ix.seg_off[t * (S + 1) + b] * 4;
+      for (uint32_t i = len; i < ((len + 3) & ~3u); i++) p[i] = p[len - 1];
+    }
   for (const auto& rd : raw_dups) ix.dups.push_back(DupEntry{rd.term, doc_card[rd.doc], rd.doc, rd.mult});
   std::sort(ix.dups.begin(), ix.dups.end(), [](const DupEntry& x, const DupEntry& y) {
     if (x.term != y.term) return x.term < y.term;

@@ -13,7 +13,6 @@
 namespace sg {
 
 constexpr uint32_t kNoTerm = 0xFFFFFFFFu;
-constexpr uint32_t kPadDoc = 0xFFFFFFFFu;  // sentinel that pads every posting list to 16 bytes
 constexpr uint32_t kRuneError = 0xFFFD;
 
 // Symbol table: every rune that can appear in a normalised term (alphabet runes + the runes of

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where do a wavefront's cycles go?  Runs the headline batch on the SG_PHASE_TIMING build of the kernel
+(s_memtime brackets per phase) and prints the share of each phase.  GPU box only:
+   make -C suggest_amd/csrc prof && python tools/phase_timing.py [--dict-size N]"""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from suggest_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "suggest_amd", "libsuggest_hip_prof.so")
+from suggest_amd import IndexDescription, NGramIndex, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dict-size", type=int, default=10_000_000)
+ap.add_argument("--queries", type=int, default=65536)
+ap.add_argument("--metric", default="jaccard")
+ap.add_argument("--similarity", type=float, default=0.5)
+ap.add_argument("--topk", type=int, default=10)
+args = ap.parse_args()
+blob, offs = synth.make_dict(args.dict_size, seed=1)
+qb, qo = synth.make_queries(args.queries, blob, offs, seed=2)
+ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
+dev = torch.device("cuda", 0)
+prof = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+L = _lib.lib()
+L.sg_debug_set_prof.argtypes = [C.c_void_p]
+L.sg_debug_set_prof(prof.data_ptr())
+k, n_q = args.topk, args.queries
+d_q = torch.from_numpy(qb).to(dev); d_offs = torch.from_numpy(qo.view(np.int64)).to(dev)
+d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
+d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
+for it in range(3):
+    prof.zero_()
+    torch.cuda.synchronize()
+    ix.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k, d_ids.data_ptr(), d_sc.data_ptr(),
+                            d_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for it in range(5):
+    ix.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k, d_ids.data_ptr(), d_sc.data_ptr(),
+                            d_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+e1.record(); torch.cuda.synchronize()
+print("SG_DEBUG_SKIP=%s kernel ms (instrumented build): %.3f" % (os.environ.get("SG_DEBUG_SKIP", "0"), e0.elapsed_time(e1) / 5))
+p = prof.cpu().numpy().astype(np.float64).reshape(4096, 8).sum(axis=0) / 6
+names = ["tokenize", "tile rows + segment stats", "group setup (merge, scan, geometry)", "clear counters", "chunk directory",
+         "stream (loads + count)", "slow path (flagged)", "top-k sort + output"]
+tot = p.sum()
+print("cycles per query (wave-time, s_memtime): %.0f" % (tot / n_q))
+for n, v in zip(names, p):
+    print("  %-40s %10.0f  %5.1f%%" % (n, v / n_q, 100 * v / tot))
