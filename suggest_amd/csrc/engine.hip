@@ -31,7 +31,6 @@ namespace sg {
 #define SG_ROWS_CAP 1024   // u32 entries of seg_off rows kept in LDS per tile
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
-#define SG_ADDR_CAP 1024   // chunk-directory entries per streaming window
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -343,65 +342,49 @@ __device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T) {
 }
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-static_assert(SG_UNROLL == 4, "u32x16 below holds 4 chunks x 4 postings");
+static_assert(SG_UNROLL == 4, "u32x16 below holds 4 rows x 4 postings");
 
-// One streaming step over up to 64*SG_UNROLL chunks whose data is already in v[]: one LDS atomic
-// per posting (U8: four u8 counters per word, else one u32 counter per word), issued back to back.
-// Returns the ballot of lanes holding a posting whose bucket reached T; `was` receives the bucket
-// counts seen (for the rare slow path).  TAIL masks lanes past the end of the stream (they re-read
-// the last chunk).
-template <bool U8, bool TAIL>
-__device__ __forceinline__ uint64_t count_step(const uint4 (&v)[SG_UNROLL], uint32_t* cnt, uint32_t c0, uint32_t L,
-                                               uint32_t bmask, uint32_t Tm1, int lane, u32x16& was) {
+// Counts one batch of SG_UNROLL rows (a row = up to 64 consecutive 16-byte chunks of ONE posting
+// list, one chunk per lane): one LDS atomic per posting (U8: four u8 counters per word, else one
+// u32 counter per word), issued back to back and waited for once.  live[u] is 1 for lanes inside
+// the list, 0 for lanes past its end (they re-read the list's last chunk and add 0).  Returns the
+// ballot of lanes holding a posting whose bucket reached T; `was` receives the counts seen.
+template <bool U8>
+__device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], uint32_t* cnt,
+                                               uint32_t bmask, uint32_t Tm1, u32x16& was) {
   uint32_t old[4 * SG_UNROLL];
   uint32_t shf[U8 ? 4 * SG_UNROLL : 1];
 #pragma unroll
   for (int u = 0; u < SG_UNROLL; u++) {
-    const uint32_t live = (!TAIL || c0 + u * 64 + lane < L) ? 1u : 0u;
     const uint32_t dv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const uint32_t b = dv[e] & bmask;
       if (U8) {
+        const uint32_t b = dv[e] & bmask;
         const uint32_t sh = (b & 3u) << 3;
         shf[u * 4 + e] = sh;
-        old[u * 4 + e] = atomicAdd(&cnt[b >> 2], live << sh);
+        old[u * 4 + e] = atomicAdd(&cnt[b >> 2], live[u] << sh);
       } else {
-        old[u * 4 + e] = atomicAdd(&cnt[b], live);
+        old[u * 4 + e] = atomicAdd(&cnt[dv[e] & bmask], live[u]);
       }
     }
   }
   uint32_t mx = 0;
 #pragma unroll
   for (int u = 0; u < SG_UNROLL; u++) {
-    const bool live = !TAIL || c0 + u * 64 + lane < L;
+    uint32_t mu = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       uint32_t o = old[u * 4 + e];
       if (U8) o = (o >> shf[u * 4 + e]) & 0xFFu;
-      if (TAIL) o = live ? o : 0u;
       was[u * 4 + e] = o;
-      mx = max(mx, o);
+      mu = max(mu, o);
     }
+    mx = max(mx, live[u] ? mu : 0u);
   }
   return ballot(mx >= Tm1);
 }
 
-// ------------------------------------------------------------------------------------------
-// The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
-//   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | lstart | lprefix | rows | addr | cand | topk
-//
-// Per query: the admissible window of cardinality segments is cut into tiles; for a tile the
-// chunk offsets seg_off[term][b] of every query term are fetched once into LDS (`rows`), lane w
-// then owns segment w of the tile (its threshold T, posting volume, number of present terms).
-// Consecutive valid segments are merged into groups (term-major CSR keeps a term's postings for
-// consecutive segments contiguous) and each group is streamed once:
-//   chunk directory addr[] built in LDS (one entry per 16-byte chunk)  ->  16-byte coalesced loads,
-//   SG_UNROLL in flight per lane and the next step's loads issued before the current step is
-//   counted  ->  one LDS atomic per posting  ->  postings whose bucket reaches T are verified
-//   exactly (binary searches in the term lists of the doc's own segment), scored and offered to
-//   the wave's top-k.
-// ------------------------------------------------------------------------------------------
 #ifdef SG_PHASE_TIMING   // tools/phase_timing.py: where do a wavefront's cycles go (s_memtime brackets)
 #define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_last = clock64();
 #define PH(n) { const long long ph_now = clock64(); ph_acc[n] += ph_now - ph_last; ph_last = ph_now; }
@@ -414,19 +397,31 @@ __device__ __forceinline__ uint64_t count_step(const uint4 (&v)[SG_UNROLL], uint
 #define PH_FLUSH
 #endif
 
+// ------------------------------------------------------------------------------------------
+// The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
+//   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | rows | cand | topk
+//
+// Per query: the admissible window of cardinality segments is cut into tiles; for a tile the
+// chunk offsets seg_off[term][b] of every query term are fetched once into LDS (`rows`), lane w
+// then owns segment w of the tile (its threshold T, posting volume, number of present terms).
+// Consecutive valid segments are merged into groups (term-major CSR keeps a term's postings for
+// consecutive segments contiguous, so a group is still one contiguous range per term) and each
+// group is streamed once, list by list: a row = 64 consecutive 16-byte chunks of one list (one
+// coalesced 1 KiB read), SG_UNROLL rows in flight and the next batch's loads issued before the
+// current batch is counted  ->  one LDS atomic per posting  ->  postings whose bucket reaches T
+// are verified exactly (binary searches in the term lists of the doc's own segment), scored and
+// offered to the wave's top-k.
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
   const uint32_t qi = blockIdx.x;
   const DeviceIndex& ix = a.ix;
   const uint32_t cnt_words = 1u << a.log2_cnt;
-  uint32_t* cnt = smem;
+  uint32_t* cnt = smem;                              // LDS address 0: counter index == ds offset
   uint32_t* term = cnt + cnt_words;
-  uint32_t* lstart = term + SG_MAX_A;
-  uint32_t* lprefix = lstart + SG_MAX_A;           // SG_MAX_A + 1 (+3 pad)
-  uint32_t* rows = lprefix + SG_MAX_A + 4;
-  uint32_t* addr = rows + SG_ROWS_CAP;
-  uint32_t* cand = addr + SG_ADDR_CAP;
+  uint32_t* rows = term + SG_MAX_A;
+  uint32_t* cand = rows + SG_ROWS_CAP;
   uint32_t* tk_id_lds = cand + SG_CAND_CAP;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
@@ -507,41 +502,30 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       if (!rest) break;
       const int g0 = __builtin_ctzll(rest);
       int g1 = g0;
-      uint32_t L_est = readlane(seg_tot, g0);
+      uint32_t L = readlane(seg_tot, g0);                     // 16-byte chunks of the group
       int Tmin = (int)readlane((uint32_t)seg_T, g0);
-      // merge following valid segments while the counters still resolve the group and its chunk
-      // directory fits in LDS
+      // merge following valid segments while the counters still resolve the group
       for (;;) {
         const int nx = g1 + 1;
         if (nx >= Wt || !((vmask >> nx) & 1)) break;
         const uint32_t nt = readlane(seg_tot, nx);
         const int tm = min(Tmin, (int)readlane((uint32_t)seg_T, nx));
-        if (L_est + nt > SG_ADDR_CAP || buckets_needed((L_est + nt) * 4u, tm) > max_buckets) break;
-        L_est += nt; Tmin = tm; g1 = nx;
+        if (buckets_needed((L + nt) * 4u, tm) > max_buckets) break;
+        L += nt; Tmin = tm; g1 = nx;
       }
       wnext = g1 + 1;
 
-      // ---- the group's lists: list i = postings of term i over segments tb+g0 .. tb+g1 ----
-      __syncthreads();
-      uint32_t running = 0;
-      uint32_t ls_r[2] = {0, 0}, ln_r[2] = {0, 0}, pb_r[2] = {0, 0};   // this lane's list (per round): start, chunks, prefix
+      // ---- the group's lists: list i = postings of term i over segments tb+g0 .. tb+g1;
+      //      lane i keeps its start chunk and chunk count (round r covers terms 64r .. 64r+63) ----
+      uint32_t ls_r[2] = {0, 0}, ln_r[2] = {0, 0};
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        if (r < a_rounds) {
-          const int i = r * 64 + lane;
-          uint32_t s = 0, len = 0;
-          if (i < A) { s = rows[i * stride + g0]; len = rows[i * stride + g1 + 1] - s; }
-          const uint32_t incl = wave_scan_incl(len, lane);
-          ls_r[r] = s; ln_r[r] = len; pb_r[r] = running + incl - len;
-          if (i < A) { lstart[i] = s; lprefix[i] = pb_r[r]; }
-          running += readlane(incl, 63);
-        }
+        const int i = r * 64 + lane;
+        if (r < a_rounds && i < A) { ls_r[r] = rows[i * stride + g0]; ln_r[r] = rows[i * stride + g1 + 1] - ls_r[r]; }
       }
-      if (lane == 0) lprefix[A] = running;
-      const uint32_t L = running;                             // 16-byte chunks to stream
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
-      // word; a u8 counter that saturates (needs > 255 postings in one bucket) re-runs the group wide.
+      // word; a u8 counter that nears saturation re-runs the group with u32 counters.
       const uint32_t need = buckets_needed(L * 4u, Tmin);
       bool u8 = need > cnt_words && Tmin <= 200;
       uint32_t lg = 8;
@@ -550,14 +534,13 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         while (lg < lg_max && (1u << lg) < need) lg++;
       }
       uint32_t ncand = 0;
-      bool overflow = false;
+      bool overflow = false, saturated = false;
 
-      // exact overlap of doc d (found in list jj at chunk cc): locate its segment, then count the
-      // query-term occurrences whose list in that segment contains d (wave-cooperative)
-      auto verify = [&](uint32_t d, uint32_t jj, uint32_t cc, int* seg_w, int* last_list) -> int {
-        const uint32_t abs = lstart[jj] + (cc - lprefix[jj]);
+      // exact overlap of doc d, found in list jj at chunk `chunk` of the posting store: locate its
+      // segment, then count the query-term occurrences whose list in that segment contains d
+      auto verify = [&](uint32_t d, uint32_t jj, uint32_t chunk, int* seg_w, int* last_list) -> int {
         int w = g0;
-        while (w < g1 && rows[jj * stride + w + 1] <= abs) w++;
+        while (w < g1 && rows[jj * stride + w + 1] <= chunk) w++;
         *seg_w = w;
         int c = 0, last = -1;
         for (int r = 0; r < a_rounds; r++) {
@@ -590,13 +573,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
         return ballot(seen) != 0;
       };
-      auto locate = [&](uint32_t cc) -> uint32_t {            // list holding chunk cc (uniform)
-        uint32_t lo = 0, hi = (uint32_t)A;
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lprefix[mid] <= cc) lo = mid; else hi = mid; }
-        return lo;
-      };
-      bool saturated = false;
-      auto on_flag = [&](uint32_t dd, uint32_t cc) {          // dd was flagged at stream position (chunk) cc
+      auto on_flag = [&](uint32_t dd, uint32_t jj, uint32_t chunk) {   // dd flagged in list jj at posting-store chunk
         if (u8) {                                              // a saturating u8 counter would carry into its neighbour
           const uint32_t b = dd & ((1u << lg) - 1u);
           if (((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) >= 250u) saturated = true;
@@ -607,87 +584,81 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         ncand++;
         __syncthreads();
         int w, last;
-        const int ov = verify(dd, locate(cc), cc, &w, &last);
+        const int ov = verify(dd, jj, chunk, &w, &last);
         emit(dd, ov, w);
       };
+      // slow path of one counted batch: rows u = 0..3 hold list jl[u] from chunk cb[u] on
+      auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
+                         const uint32_t (&jl)[SG_UNROLL], const uint32_t (&cb)[SG_UNROLL], uint32_t Tm1) {
+        const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                           v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+        const uint32_t __attribute__((ext_vector_type(4))) lv = {live[0], live[1], live[2], live[3]};
+        const uint32_t __attribute__((ext_vector_type(4))) jv = {jl[0], jl[1], jl[2], jl[3]};
+        const uint32_t __attribute__((ext_vector_type(4))) cv = {cb[0], cb[1], cb[2], cb[3]};
+#pragma nounroll
+        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {            // uniform dynamic index into the register vectors
+          uint64_t m = ballot(lv[ue >> 2] && was[ue] >= Tm1);
+          const uint32_t dsel = vv[ue];
+          const uint32_t jj = jv[ue >> 2], c0 = cv[ue >> 2];
+          while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            on_flag(readlane(dsel, l), jj, c0 + (uint32_t)l);
+          }
+        }
+      };
 
-      // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
       PH(2)
+      // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
-        if (!DBG_SKIP(1u))
         for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
         const uint32_t bmask = (1u << lg) - 1u, Tm1 = (uint32_t)Tmin - 1u;
-        for (uint32_t w0 = 0; w0 < L; w0 += SG_ADDR_CAP) {    // windows of the chunk directory
-          const uint32_t Lw = min((uint32_t)SG_ADDR_CAP, L - w0);
-          __syncthreads();
-          PH(3)
-          // chunk directory: addr[c - w0] = global chunk index of stream position c
-          if (DBG_SKIP(2u)) {
-          } else if (L >= 16u * (uint32_t)A) {                  // long lists: the wave walks each list
-            const bool one_window = L <= SG_ADDR_CAP;
-            for (int i = 0; i < A; i++) {
-              const int r = i >> 6, li = i & 63;
-              const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li),
-                             pb = readlane(r ? pb_r[1] : pb_r[0], li);
-              if (one_window) {
-                if ((uint32_t)lane < n) addr[pb + lane] = s + lane;
-                if (n > 64) for (uint32_t kk = 64 + lane; kk < n; kk += 64) addr[pb + kk] = s + kk;
-              } else {
-                if (pb + n <= w0 || pb >= w0 + Lw) continue;
-                const uint32_t k0 = pb < w0 ? w0 - pb : 0u, k1 = min(n, w0 + Lw - pb);
-                for (uint32_t kk = k0 + lane; kk < k1; kk += 64) addr[pb + kk - w0] = s + kk;
-              }
-            }
-          } else {                                              // short lists: one lane per list
+        __syncthreads();
+        PH(3)
+        // Row iterator (wave-uniform state): rows of 64 chunks, list after list, SG_UNROLL rows per
+        // batch across list boundaries; the next batch's loads are issued before the current one is counted.
+        uint64_t todo0 = ballot(ln_r[0] != 0), todo1 = a_rounds > 1 ? ballot(ln_r[1] != 0) : 0ull;
+        uint32_t cur_s = 0, cur_n = 0, cur_c0 = 0, cur_j = 0;
+        uint4 v[SG_UNROLL], vn[SG_UNROLL];
+        uint32_t live[SG_UNROLL], liven[SG_UNROLL], jl[SG_UNROLL], jln[SG_UNROLL], cb[SG_UNROLL], cbn[SG_UNROLL];
+        u32x16 was;
+        auto fetch = [&](uint4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL], uint32_t (&jj)[SG_UNROLL], uint32_t (&cc)[SG_UNROLL]) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-              if (r < a_rounds) {
-                const uint32_t s = ls_r[r], n = ln_r[r], pb = pb_r[r];
-                const uint32_t k0 = pb < w0 ? min(n, w0 - pb) : 0u, k1 = pb >= w0 + Lw ? 0u : min(n, w0 + Lw - pb);
-                for (uint32_t kk = k0; kk < k1; kk++) addr[pb + kk - w0] = s + kk;
-              }
+          for (int u = 0; u < SG_UNROLL; u++) {
+            if (cur_c0 >= cur_n) {                              // next non-empty list
+              if (todo0) {
+                const int li = __builtin_ctzll(todo0);
+                todo0 &= todo0 - 1;
+                cur_s = readlane(ls_r[0], li); cur_n = readlane(ln_r[0], li); cur_j = (uint32_t)li; cur_c0 = 0;
+              } else if (todo1) {
+                const int li = __builtin_ctzll(todo1);
+                todo1 &= todo1 - 1;
+                cur_s = readlane(ls_r[1], li); cur_n = readlane(ln_r[1], li); cur_j = 64u + (uint32_t)li; cur_c0 = 0;
+              } else { cur_n = 0; cur_c0 = 0; }                 // no rows left: dead row (adds 0)
             }
+            const uint32_t c = cur_c0 + (uint32_t)lane;
+            lv[u] = c < cur_n ? 1u : 0u;
+            jj[u] = cur_j;
+            cc[u] = cur_s + cur_c0;
+            vv[u] = post4[cur_s + min(c, cur_n ? cur_n - 1 : 0u)];
+            cur_c0 += 64;
           }
-          __syncthreads();
-          PH(4)
-          // stream the window: loads of step i+1 are issued before step i is counted
-          uint4 v[SG_UNROLL], vn[SG_UNROLL];
-          u32x16 was;
+        };
+        bool have_batch = (todo0 | todo1) != 0;
+        if (have_batch) fetch(v, live, jl, cb);
+        while (have_batch) {
+          const bool more = (todo0 | todo1) != 0 || cur_c0 < cur_n;
+          if (more) fetch(vn, liven, jln, cbn);
+          uint64_t any = 0;
+          if (DBG_SKIP(4u)) asm volatile("" :: "v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x));
+          else any = u8 ? count_rows<true>(v, live, cnt, bmask, Tm1, was) : count_rows<false>(v, live, cnt, bmask, Tm1, was);
+          if (any) { PH(5) flagged(v, live, was, jl, cb, Tm1); PH(6) }
+          if (more) {
 #pragma unroll
-          for (int u = 0; u < SG_UNROLL; u++) v[u] = post4[addr[min((uint32_t)(u * 64 + lane), Lw - 1)]];
-          for (uint32_t c0 = 0; c0 < Lw; c0 += 64 * SG_UNROLL) {
-            const bool more = c0 + 64 * SG_UNROLL < Lw;
-            if (more) {
-#pragma unroll
-              for (int u = 0; u < SG_UNROLL; u++) vn[u] = post4[addr[min(c0 + 64 * SG_UNROLL + u * 64 + lane, Lw - 1)]];
-            }
-            const bool tail = c0 + 64 * SG_UNROLL > Lw;
-            uint64_t any;
-            if (DBG_SKIP(4u)) { any = 0; asm volatile("" :: "v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x)); }
-            else if (u8) any = tail ? count_step<true, true>(v, cnt, c0, Lw, bmask, Tm1, lane, was) : count_step<true, false>(v, cnt, c0, Lw, bmask, Tm1, lane, was);
-            else any = tail ? count_step<false, true>(v, cnt, c0, Lw, bmask, Tm1, lane, was) : count_step<false, false>(v, cnt, c0, Lw, bmask, Tm1, lane, was);
-            if (any) {                                          // rare; wave-uniform
-              PH(5)
-              const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
-                                 v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
-#pragma nounroll
-              for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {      // uniform dynamic index into the register vectors
-                uint64_t m = ballot(was[ue] >= Tm1);
-                const uint32_t dsel = vv[ue];
-                while (m) {
-                  const int l = __builtin_ctzll(m);
-                  m &= m - 1;
-                  on_flag(readlane(dsel, l), w0 + c0 + (uint32_t)(ue >> 2) * 64 + (uint32_t)l);
-                }
-              }
-              PH(6)
-            }
-            if (more) {
-#pragma unroll
-              for (int u = 0; u < SG_UNROLL; u++) v[u] = vn[u];
-            }
+            for (int u = 0; u < SG_UNROLL; u++) { v[u] = vn[u]; live[u] = liven[u]; jl[u] = jln[u]; cb[u] = cbn[u]; }
           }
+          have_batch = more;
         }
         PH(5)
         if (!(u8 && saturated)) break;
@@ -702,31 +673,33 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         // every remaining doc is handled exactly once, at its occurrence in the last list holding it
         // (padding repeats a list's last doc inside its last chunk: skipped as equal neighbours).
         __syncthreads();
-        for (uint32_t c0 = 0; c0 < L; c0 += 64) {
-          const uint32_t c = c0 + lane;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          uint32_t lo = 0;
-          if (c < L) { lo = locate(c); v = post4[lstart[lo] + (c - lprefix[lo])]; }
-          const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < A; i++) {
+          const int r = i >> 6, li = i & 63;
+          const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li);
+          for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < n) v = post4[s + c];
+            const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const uint32_t d = dv[e];
-            bool flag = false;
-            if (c < L && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
-              const uint32_t b = d & ((1u << lg) - 1u);
-              const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[b];
-              flag = now >= (uint32_t)Tmin;
-            }
-            uint64_t m = ballot(flag);
-            while (m) {
-              const int l = __builtin_ctzll(m);
-              m &= m - 1;
-              const uint32_t dd = readlane(d, l);
-              const uint32_t jj = readlane(lo, l);
-              if (in_cand(dd)) continue;
-              int w, last;
-              const int ov = verify(dd, jj, c0 + l, &w, &last);
-              if (last == (int)jj) emit(dd, ov, w);
+            for (int e = 0; e < 4; e++) {
+              const uint32_t d = dv[e];
+              bool flag = false;
+              if (c < n && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
+                const uint32_t b = d & ((1u << lg) - 1u);
+                const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[b];
+                flag = now >= (uint32_t)Tmin;
+              }
+              uint64_t m = ballot(flag);
+              while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t dd = readlane(d, l);
+                if (in_cand(dd)) continue;
+                int w, last;
+                const int ov = verify(dd, (uint32_t)i, s + c0 + (uint32_t)l, &w, &last);
+                if (last == i) emit(dd, ov, w);
+              }
             }
           }
         }
@@ -806,7 +779,7 @@ const LowerPair kLowerPairs[] = {
 };
 
 size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A * 3 + 4 + SG_ROWS_CAP + SG_ADDR_CAP + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
+  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
