@@ -31,6 +31,7 @@ namespace sg {
 #define SG_ROWS_CAP 1024   // u32 entries of seg_off rows kept in LDS per tile
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
+#define SG_T_FLOOR 8       // lowest flag threshold list skipping may leave
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -334,7 +335,7 @@ __device__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
 }
 
 // Buckets a group of `postings` postings needs so that a bucket reaching T by chance is rare
-// (expected false buckets per group ~<= 0.1): postings / lambda(T).
+// (a false candidate only costs a slot in the batched verification): postings / lambda(T).
 __device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T) {
   // 16/lambda(T) with lambda = 4, 3.2, 2, 1.23, 0.5, 0.31, 0.125 postings per bucket
   const uint32_t m16 = T >= 14 ? 4u : T >= 12 ? 5u : T >= 10 ? 8u : T >= 8 ? 13u : T >= 6 ? 32u : T == 5 ? 51u : 128u;
@@ -388,10 +389,15 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 #ifdef SG_PHASE_TIMING   // tools/phase_timing.py: where do a wavefront's cycles go (s_memtime brackets)
 #define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_last = clock64();
 #define PH(n) { const long long ph_now = clock64(); ph_acc[n] += ph_now - ph_last; ph_last = ph_now; }
-#define PH_FLUSH if (lane < 8 && a.prof) { atomicAdd(a.prof + (qi & 4095u) * 8 + lane, (unsigned long long)ph_acc[lane]); }
+#define PH_FLUSH if (lane < 8 && a.prof) { atomicAdd(a.prof + (qi & 4095u) * 8 + lane, (unsigned long long)ph_acc[lane]); \
+                                             atomicAdd(a.prof + 4096 * 8 + (qi & 4095u) * 8 + lane, (unsigned long long)dbg_n[lane]); }
 #define DBG_SKIP(bit) (a.dbg_skip & (bit))
+#define DBG_COUNT(slot, v) dbg_n[slot] += (v);
+#define DBG_DECL long long dbg_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #else
 #define DBG_SKIP(bit) false
+#define DBG_COUNT(slot, v)
+#define DBG_DECL
 #define PH_DECL
 #define PH(n)
 #define PH_FLUSH
@@ -399,7 +405,7 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 
 // ------------------------------------------------------------------------------------------
 // The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
-//   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | rows | cand | topk
+//   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | rows | cand, candw | topk
 //
 // Per query: the admissible window of cardinality segments is cut into tiles; for a tile the
 // chunk offsets seg_off[term][b] of every query term are fetched once into LDS (`rows`), lane w
@@ -422,7 +428,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* term = cnt + cnt_words;
   uint32_t* rows = term + SG_MAX_A;
   uint32_t* cand = rows + SG_ROWS_CAP;
-  uint32_t* tk_id_lds = cand + SG_CAND_CAP;
+  uint32_t* candw = cand + SG_CAND_CAP;             // segment (within the tile) of each queued candidate
+  uint32_t* tk_id_lds = candw + SG_CAND_CAP;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
   PH_DECL
+  DBG_DECL
   if (DBG_SKIP(32u)) { if (lane == 0) a.out_counts[qi] = 0; return; }
   const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
   PH(0)
@@ -496,6 +504,71 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     const uint64_t vmask = ballot(seg_valid);
     PH(1)
 
+    // ---- candidate queue of the tile: docs whose bucket reached the flag threshold wait here and are
+    //      verified together (their binary searches overlap in flight) instead of stalling the stream ----
+    uint32_t qn = 0;
+    auto emit = [&](uint32_t d, int overlap, int w) {
+      const int T = (int)readlane((uint32_t)seg_T, w);
+      if (overlap < T) return;
+      DBG_COUNT(5, 1)
+      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
+      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
+    };
+    auto flush_queue = [&]() {
+      __syncthreads();
+      DBG_COUNT(4, qn ? 1 : 0)
+      for (uint32_t c0 = 0; c0 < qn; c0 += 4) {                  // 4 candidates x A lists searched interleaved
+        uint32_t qd[4], qw[4];
+        bool ok[4];
+        int ov[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { ok[j] = c0 + j < qn; qd[j] = ok[j] ? cand[c0 + j] : 0u; qw[j] = ok[j] ? candw[c0 + j] : 0u; }
+        for (int r = 0; r < a_rounds; r++) {
+          const int i = r * 64 + lane;
+          uint32_t lo[4], hi[4], n4[4];
+          const uint32_t* pp[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            lo[j] = 0; hi[j] = 0; n4[j] = 0; pp[j] = ix.postings;
+            if (i < A && ok[j]) {
+              const uint32_t s0 = rows[i * stride + qw[j]];
+              n4[j] = (rows[i * stride + qw[j] + 1] - s0) * 4u;
+              hi[j] = n4[j];
+              pp[j] = ix.postings + (uint64_t)s0 * 4;
+            }
+          }
+          for (int step = 0; step < 32; step++) {
+            bool act = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (lo[j] < hi[j]) {
+                const uint32_t mid = (lo[j] + hi[j]) >> 1;
+                if (pp[j][mid] < qd[j]) lo[j] = mid + 1; else hi[j] = mid;
+                act = true;
+              }
+            }
+            if (!ballot(act)) break;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool found = lo[j] < n4[j] && pp[j][lo[j]] == qd[j];
+            ov[j] += (int)popc64(ballot(found));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (ok[j]) emit(qd[j], ov[j], (int)qw[j]);
+      }
+      qn = 0;
+    };
+
+    // buckets a group needs once its longest lists are skipped down to SG_T_FLOOR (estimate: equal lengths)
+    const float inv_A = 1.0f / (float)A;
+    auto need_after_skip = [&](uint32_t chunks, int T) -> uint32_t {
+      const int k = (T > SG_T_FLOOR && !DBG_SKIP(8u)) ? min(T - SG_T_FLOOR, A - 1) : 0;
+      const uint32_t rem = chunks - (uint32_t)((float)chunks * (float)k * inv_A);
+      return buckets_needed(rem * 4u, T - k);
+    };
+
     int wnext = DBG_SKIP(16u) ? Wt : 0;
     while (wnext < Wt) {
       const uint64_t rest = (vmask >> wnext) << wnext;
@@ -510,7 +583,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         if (nx >= Wt || !((vmask >> nx) & 1)) break;
         const uint32_t nt = readlane(seg_tot, nx);
         const int tm = min(Tmin, (int)readlane((uint32_t)seg_T, nx));
-        if (buckets_needed((L + nt) * 4u, tm) > max_buckets) break;
+        if (need_after_skip(L + nt, tm) > max_buckets) break;
         L += nt; Tmin = tm; g1 = nx;
       }
       wnext = g1 + 1;
@@ -523,17 +596,56 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         const int i = r * 64 + lane;
         if (r < a_rounds && i < A) { ls_r[r] = rows[i * stride + g0]; ln_r[r] = rows[i * stride + g1 + 1] - ls_r[r]; }
       }
+      // ---- skip the longest lists (the pigeonhole behind CPMerge, cp_merge.go:22-31): a doc that is
+      //      in >= T of the n lists is in >= T-k of ANY n-k of them, so k lists need not be streamed
+      //      if postings are flagged at T-k; the exact overlap always comes from the verification over
+      //      all lists.  Any k lists are valid; up to T - SG_T_FLOOR lists are taken in tiers of
+      //      relative length (> 3x, 2x, 1.5x, 1x, 0.75x, 0.5x the mean), longest tiers first. ----
+      uint64_t skip_m[2] = {0, 0};
+      int Teff = Tmin;
+      uint32_t Leff = L;
+      if (Tmin > SG_T_FLOOR && !DBG_SKIP(8u)) {
+        const int k_allowed = Tmin - SG_T_FLOOR;
+        const uint32_t n_ne = popc64(ballot(ln_r[0] != 0)) + (a_rounds > 1 ? popc64(ballot(ln_r[1] != 0)) : 0u);
+        const uint32_t x0 = ln_r[0] * n_ne, x1 = ln_r[1] * n_ne;
+        const uint32_t th[6] = {L * 3u, L * 2u, L + (L >> 1), L, L - (L >> 2), L >> 1};
+        uint64_t pick0 = 0, pick1 = 0;
+        int budget = k_allowed;
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+          if (budget > 0) {
+            uint64_t m0 = ballot(x0 > th[f]) & ~pick0;
+            while ((int)popc64(m0) > budget) m0 &= ~(1ull << (63 - __builtin_clzll(m0)));
+            pick0 |= m0; budget -= (int)popc64(m0);
+            if (a_rounds > 1 && budget > 0) {
+              uint64_t m1 = ballot(x1 > th[f]) & ~pick1;
+              while ((int)popc64(m1) > budget) m1 &= ~(1ull << (63 - __builtin_clzll(m1)));
+              pick1 |= m1; budget -= (int)popc64(m1);
+            }
+          }
+        }
+        const int k_skip = (int)(popc64(pick0) + popc64(pick1));
+        if (k_skip > 0) {
+          const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
+          const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
+          if (buckets_needed((L - skipped) * 4u, Tmin - k_skip) <= max_buckets) {
+            skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
+          }
+        }
+      }
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = buckets_needed(L * 4u, Tmin);
-      bool u8 = need > cnt_words && Tmin <= 200;
+      const uint32_t need = buckets_needed(Leff * 4u, Teff);
+      bool u8 = need > cnt_words && Teff <= 200;
       uint32_t lg = 8;
       {
         const uint32_t lg_max = u8 ? a.log2_cnt + 2 : a.log2_cnt;
         while (lg < lg_max && (1u << lg) < need) lg++;
       }
-      uint32_t ncand = 0;
+      if (qn > SG_CAND_CAP - 16) flush_queue();
+      DBG_COUNT(0, 1) DBG_COUNT(6, L - Leff) DBG_COUNT(7, L)
+      const uint32_t q0 = qn;                                  // this group's candidates: cand[q0 .. qn)
       bool overflow = false, saturated = false;
 
       // exact overlap of doc d, found in list jj at chunk `chunk` of the posting store: locate its
@@ -562,15 +674,9 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         *last_list = last;
         return c;
       };
-      auto emit = [&](uint32_t d, int overlap, int w) {
-        const int T = (int)readlane((uint32_t)seg_T, w);
-        if (overlap < T) return;
-        if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);       // score = -docID, collector.go:104-106
-        else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
-      };
       auto in_cand = [&](uint32_t dd) -> bool {
         bool seen = false;
-        for (uint32_t i = lane; i < ncand; i += 64) seen |= cand[i] == dd;
+        for (uint32_t i = q0 + lane; i < qn; i += 64) seen |= cand[i] == dd;
         return ballot(seen) != 0;
       };
       auto on_flag = [&](uint32_t dd, uint32_t jj, uint32_t chunk) {   // dd flagged in list jj at posting-store chunk
@@ -579,13 +685,13 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           if (((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) >= 250u) saturated = true;
         }
         if (in_cand(dd)) return;
-        if (ncand == SG_CAND_CAP) { overflow = true; return; }
-        if (lane == 0) cand[ncand] = dd;
-        ncand++;
+        if (qn == SG_CAND_CAP) { overflow = true; return; }
+        int w = g0;                                            // segment of dd: where list jj holds `chunk`
+        while (w < g1 && rows[jj * stride + w + 1] <= chunk) w++;
+        if (lane == 0) { cand[qn] = dd; candw[qn] = (uint32_t)w; }
+        qn++;
+        DBG_COUNT(3, 1)
         __syncthreads();
-        int w, last;
-        const int ov = verify(dd, jj, chunk, &w, &last);
-        emit(dd, ov, w);
       };
       // slow path of one counted batch: rows u = 0..3 hold list jl[u] from chunk cb[u] on
       auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
@@ -603,6 +709,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           while (m) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
+            DBG_COUNT(2, 1)
             on_flag(readlane(dsel, l), jj, c0 + (uint32_t)l);
           }
         }
@@ -613,12 +720,12 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
         for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
-        const uint32_t bmask = (1u << lg) - 1u, Tm1 = (uint32_t)Tmin - 1u;
+        const uint32_t bmask = (1u << lg) - 1u, Tm1 = (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
         // Row iterator (wave-uniform state): rows of 64 chunks, list after list, SG_UNROLL rows per
         // batch across list boundaries; the next batch's loads are issued before the current one is counted.
-        uint64_t todo0 = ballot(ln_r[0] != 0), todo1 = a_rounds > 1 ? ballot(ln_r[1] != 0) : 0ull;
+        uint64_t todo0 = ballot(ln_r[0] != 0) & ~skip_m[0], todo1 = a_rounds > 1 ? ballot(ln_r[1] != 0) & ~skip_m[1] : 0ull;
         uint32_t cur_s = 0, cur_n = 0, cur_c0 = 0, cur_j = 0;
         uint4 v[SG_UNROLL], vn[SG_UNROLL];
         uint32_t live[SG_UNROLL], liven[SG_UNROLL], jl[SG_UNROLL], jln[SG_UNROLL], cb[SG_UNROLL], cbn[SG_UNROLL];
@@ -645,20 +752,27 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
             cur_c0 += 64;
           }
         };
-        bool have_batch = (todo0 | todo1) != 0;
-        if (have_batch) fetch(v, live, jl, cb);
-        while (have_batch) {
-          const bool more = (todo0 | todo1) != 0 || cur_c0 < cur_n;
-          if (more) fetch(vn, liven, jln, cbn);
+        // ping-pong between two register sets: the next batch's loads are in flight while one is counted
+        auto rows_left = [&]() -> bool { return (todo0 | todo1) != 0 || cur_c0 < cur_n; };
+        auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], const uint32_t (&pj)[SG_UNROLL],
+                           const uint32_t (&pc)[SG_UNROLL]) {
           uint64_t any = 0;
-          if (DBG_SKIP(4u)) asm volatile("" :: "v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x));
-          else any = u8 ? count_rows<true>(v, live, cnt, bmask, Tm1, was) : count_rows<false>(v, live, cnt, bmask, Tm1, was);
-          if (any) { PH(5) flagged(v, live, was, jl, cb, Tm1); PH(6) }
-          if (more) {
-#pragma unroll
-            for (int u = 0; u < SG_UNROLL; u++) { v[u] = vn[u]; live[u] = liven[u]; jl[u] = jln[u]; cb[u] = cbn[u]; }
-          }
-          have_batch = more;
+          if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
+          else any = u8 ? count_rows<true>(pv, pl, cnt, bmask, Tm1, was) : count_rows<false>(pv, pl, cnt, bmask, Tm1, was);
+          DBG_COUNT(1, 1)
+          if (any) { PH(5) flagged(pv, pl, was, pj, pc, Tm1); PH(6) }
+        };
+        bool have = rows_left();
+        if (have) fetch(v, live, jl, cb);
+        while (have) {
+          bool more = rows_left();
+          if (more) fetch(vn, liven, jln, cbn);
+          process(v, live, jl, cb);
+          if (!more) break;
+          more = rows_left();
+          if (more) fetch(v, live, jl, cb);
+          process(vn, liven, jln, cbn);
+          have = more;
         }
         PH(5)
         if (!(u8 && saturated)) break;
@@ -688,7 +802,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
               if (c < n && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
                 const uint32_t b = d & ((1u << lg) - 1u);
                 const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[b];
-                flag = now >= (uint32_t)Tmin;
+                flag = now >= (uint32_t)Teff;
               }
               uint64_t m = ballot(flag);
               while (m) {
@@ -705,6 +819,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         }
       }
     }
+    flush_queue();
   }
 
   // ---- GetCandidates (topk.go:127-147): best first (rank sort, out of place) ----
@@ -779,7 +894,7 @@ const LowerPair kLowerPairs[] = {
 };
 
 size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP + SG_K_LDS + SG_K_LDS * 2;
+  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 

@@ -22,7 +22,7 @@ blob, offs = synth.make_dict(args.dict_size, seed=1)
 qb, qo = synth.make_queries(args.queries, blob, offs, seed=2)
 ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
 dev = torch.device("cuda", 0)
-prof = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+prof = torch.zeros(2 * 4096 * 8, dtype=torch.int64, device=dev)
 L = _lib.lib()
 L.sg_debug_set_prof.argtypes = [C.c_void_p]
 L.sg_debug_set_prof(prof.data_ptr())
@@ -43,7 +43,10 @@ for it in range(5):
                             d_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 e1.record(); torch.cuda.synchronize()
 print("SG_DEBUG_SKIP=%s kernel ms (instrumented build): %.3f" % (os.environ.get("SG_DEBUG_SKIP", "0"), e0.elapsed_time(e1) / 5))
-p = prof.cpu().numpy().astype(np.float64).reshape(4096, 8).sum(axis=0) / 6
+allp = prof.cpu().numpy().astype(np.float64).reshape(2, 4096, 8).sum(axis=1) / 6
+p = allp[0]
+cn = allp[1] / n_q
+print('per query: groups %.1f batches %.1f flag_events %.1f queued %.2f flushes %.2f emitted %.2f skipped_chunks %.0f of %.0f' % tuple(cn))
 names = ["tokenize", "tile rows + segment stats", "group setup (merge, scan, geometry)", "clear counters", "chunk directory",
          "stream (loads + count)", "slow path (flagged)", "top-k sort + output"]
 tot = p.sum()
