@@ -45,7 +45,7 @@ struct DeviceIndex {
   const uint32_t* lower_from;
   const uint32_t* lower_to;
   uint32_t slot_mask, n_na, n_lower;
-  uint32_t S, n_terms, q;
+  uint32_t S, n_terms, q, n_docs;
   uint32_t wrap0[SG_WRAP_MAX], wrap1[SG_WRAP_MAX];
   uint32_t n_wrap0, n_wrap1, n_pad;
   uint8_t pad_sym[8];
@@ -716,6 +716,36 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       };
 
       PH(2)
+      // ---- docID-range passes: a single segment whose postings outnumber what the counters resolve
+      //      (long lists: q = 2, skewed terms) is streamed in R passes over disjoint docID ranges.  Lists
+      //      are ascending, so a range is one contiguous run of chunks per list (rounded outwards to whole
+      //      chunks: every doc of the range is seen completely in its own pass). ----
+      uint32_t n_pass = 1;
+      if (g0 == g1) { while (n_pass < 1024u && need > max_buckets * n_pass) n_pass <<= 1; }
+      const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
+      uint32_t prev_e[2] = {0, 0};                              // per list: first posting of the current docID range
+      uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;
+      for (uint32_t pass = 0; pass < n_pass; pass++) {
+      if (n_pass > 1) {
+        lo_doc = (uint32_t)(((uint64_t)ix.n_docs * pass) / n_pass);
+        hi_doc = pass + 1 == n_pass ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)ix.n_docs * (pass + 1)) / n_pass);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          uint32_t e = full_ln[r] * 4;                          // first posting with doc >= hi_doc
+          if (pass + 1 != n_pass && full_ln[r]) {
+            const uint32_t* p = ix.postings + (uint64_t)full_ls[r] * 4;
+            uint32_t lo = prev_e[r], hi = full_ln[r] * 4;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[mid] < hi_doc) lo = mid + 1; else hi = mid; }
+            e = lo;
+          }
+          const uint32_t c_start = prev_e[r] >> 2, c_end = (e + 3) >> 2;   // rounded outwards to whole chunks
+          ls_r[r] = full_ls[r] + c_start;
+          ln_r[r] = c_end - c_start;
+          prev_e[r] = e;
+        }
+        lg = u8 ? a.log2_cnt + 2 : a.log2_cnt;                 // all buckets for every pass
+        overflow = false;
+      }
       // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
@@ -812,12 +842,13 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
                 if (in_cand(dd)) continue;
                 int w, last;
                 const int ov = verify(dd, (uint32_t)i, s + c0 + (uint32_t)l, &w, &last);
-                if (last == i) emit(dd, ov, w);
+                if (last == i && dd >= lo_doc && dd < hi_doc) emit(dd, ov, w);
               }
             }
           }
         }
       }
+      }  // docID-range passes
     }
     flush_queue();
   }
@@ -988,6 +1019,7 @@ int sg_index_upload(sg_index* ix, int device) {
   d.n_na = (uint32_t)h.sym.na_rune.size();
   d.n_lower = (uint32_t)lf.size();
   d.S = h.n_segments;
+  d.n_docs = (uint32_t)h.n_docs;
   d.n_terms = (uint32_t)h.term_key.size();
   d.q = h.q;
   d.n_wrap0 = (uint32_t)h.wrap0.size();

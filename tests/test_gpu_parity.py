@@ -59,6 +59,21 @@ def test_synthetic_q2_long_lists():
                 ora.suggest_batch(qb, qo, "dice", 0.5, 10))
 
 
+def test_docid_range_passes_on_heavy_segments(monkeypatch):
+    """q=2 on 1M strings with the smallest counter array: a segment's postings outnumber what the counters
+    resolve, so the kernel streams it in several docID-range passes (engine.hip, n_pass > 1)."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    monkeypatch.setenv("SG_LOG2_CNT", "9")
+    desc = dict(synth.DESCRIPTION, ngram_size=2)
+    blob, offs = synth.make_dict(1000000, seed=5)
+    qb, qo = synth.make_queries(256, blob, offs, seed=6)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+    for metric, alpha in (("dice", 0.5), ("jaccard", 0.4), ("cosine", 0.3)):
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=10),
+                    ora.suggest_batch(qb, qo, metric, alpha, 10))
+
+
 def test_large_k_uses_hbm_rows(synth_small):
     gpu, ora, qb, qo = synth_small
     assert_same(gpu.suggest_batch(blob=qb[:int(qo[256])], offs=qo[:257], metric="cosine", similarity=0.3, k=200),
