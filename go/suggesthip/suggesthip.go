@@ -1,0 +1,199 @@
+// Package suggesthip plugs libsuggest_hip.so (MI355X engine) into suggest-go behind the reference's own
+// extension seam: it implements suggest.Builder (pkg/suggest/ngram_index_builder.go:14-17) and
+// suggest.NGramIndex = Suggester + Autocomplete (pkg/suggest/ngram_index.go:7-10), so
+// Service.AddIndex / Suggest / Autocomplete callers (pkg/suggest/service.go:78-173) are unchanged.
+//
+// NOT compiled in this repository (no Go toolchain in the build image); shipped as the binding a
+// maintainer adds next to pkg/suggest.  Build: CGO_ENABLED=1, -I<repo>/include, -L<repo>/suggest_amd.
+package suggesthip
+
+/*
+#cgo LDFLAGS: -lsuggest_hip
+#include <stdlib.h>
+#include "suggest_hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"github.com/suggest-go/suggest/pkg/dictionary"
+	"github.com/suggest-go/suggest/pkg/merger"
+	"github.com/suggest-go/suggest/pkg/metric"
+	"github.com/suggest-go/suggest/pkg/suggest"
+)
+
+// Builder builds a GPU index from a dictionary and an IndexDescription (suggest.Builder).
+type Builder struct {
+	Dict        dictionary.Dictionary
+	Description suggest.IndexDescription
+	Device      int
+}
+
+// Build tokenises the dictionary on the host, lays out the CSR and uploads it to HBM.
+func (b *Builder) Build() (suggest.NGramIndex, error) {
+	var blob []byte
+	offs := []C.uint64_t{0}
+	err := b.Dict.Iterate(func(_ dictionary.Key, v dictionary.Value) error {
+		blob = append(blob, v...)
+		offs = append(offs, C.uint64_t(len(blob)))
+		return nil
+	})
+	if err != nil {
+		return nil, err
+	}
+	d := b.Description
+	alpha := make([]*C.char, len(d.Alphabet))
+	for i, a := range d.Alphabet {
+		alpha[i] = C.CString(a)
+		defer C.free(unsafe.Pointer(alpha[i]))
+	}
+	w0, w1, pad := C.CString(d.Wrap[0]), C.CString(d.Wrap[1]), C.CString(d.Pad)
+	defer C.free(unsafe.Pointer(w0))
+	defer C.free(unsafe.Pointer(w1))
+	defer C.free(unsafe.Pointer(pad))
+	// the descriptor lives in C memory for the duration of the call (cgo pointer rules)
+	desc := (*C.sg_desc)(C.malloc(C.size_t(unsafe.Sizeof(C.sg_desc{}))))
+	defer C.free(unsafe.Pointer(desc))
+	arr := (**C.char)(C.malloc(C.size_t(len(alpha)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	copy(unsafe.Slice(arr, len(alpha)), alpha)
+	desc.ngram_size, desc.wrap_start, desc.wrap_end, desc.pad = C.uint32_t(d.NGramSize), w0, w1, pad
+	desc.alphabet, desc.n_alphabet = arr, C.uint32_t(len(alpha))
+
+	var h *C.sg_index
+	var bp *C.uint8_t
+	if len(blob) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
+	}
+	if rc := C.sg_index_build(bp, &offs[0], C.uint32_t(len(offs)-1), desc, &h); rc != 0 {
+		return nil, lastError(rc)
+	}
+	if rc := C.sg_index_upload(h, C.int(b.Device)); rc != 0 {
+		C.sg_index_release(h)
+		return nil, lastError(rc)
+	}
+	ix := &Index{h: h}
+	runtime.SetFinalizer(ix, func(i *Index) { C.sg_index_release(i.h) }) // cf. pkg/index/index_reader.go:49-51
+	return ix, nil
+}
+
+// Index is the GPU-resident NGramIndex.
+type Index struct{ h *C.sg_index }
+
+func lastError(rc C.int) error { return fmt.Errorf("suggest_hip %d: %s", int(rc), C.GoString(C.sg_last_error())) }
+
+// metricCode recovers the metric behaviourally: the Metric interface is opaque at this seam
+// (unexported types), but its four methods identify it on two probe points.
+func metricCode(m metric.Metric) (C.int, error) {
+	probes := []struct {
+		code C.int
+		m    metric.Metric
+	}{{C.SG_JACCARD, metric.JaccardMetric()}, {C.SG_COSINE, metric.CosineMetric()}, {C.SG_DICE, metric.DiceMetric()},
+		{C.SG_EXACT, metric.ExactMetric()}, {C.SG_OVERLAP, metric.OverlapMetric()}}
+	for _, p := range probes {
+		if m.Threshold(0.37, 11, 17) == p.m.Threshold(0.37, 11, 17) && m.MinY(0.37, 11) == p.m.MinY(0.37, 11) &&
+			m.MaxY(0.37, 11) == p.m.MaxY(0.37, 11) && m.Distance(5, 11, 17) == p.m.Distance(5, 11, 17) {
+			return p.code, nil
+		}
+	}
+	return 0, errors.New("suggesthip: unsupported metric implementation")
+}
+
+// topK recovers k from the collector-manager factory (the closure hides it, pkg/suggest/collector.go:143-149):
+// a fresh manager's queue accepts exactly k distinct candidates.
+func topK(factory suggest.CollectorManagerFactory) int {
+	mgr := factory()
+	for k := 1; k <= 1024; k++ {
+		c := mgr.Create()
+		c.SetScorer(constScorer(float64(k)))
+		_ = c.Collect(merger.NewMergeCandidate(uint32(k), 1))
+		_ = mgr.Collect(c)
+		if len(mgr.GetCandidates()) < k {
+			return k - 1
+		}
+	}
+	return 1024
+}
+
+type constScorer float64
+
+func (s constScorer) Score(merger.MergeCandidate) float64 { return float64(s) }
+
+// Suggest implements suggest.Suggester (pkg/suggest/suggester.go:17-20) as a batch of one.
+func (i *Index) Suggest(query string, similarity float64, m metric.Metric, factory suggest.CollectorManagerFactory) ([]suggest.Candidate, error) {
+	res, err := i.SuggestBatch([]string{query}, similarity, m, topK(factory))
+	if err != nil {
+		return nil, err
+	}
+	return res[0], nil
+}
+
+// SuggestBatch is the additive API the GPU earns its keep on: one kernel launch for all queries.
+func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metric, k int) ([][]suggest.Candidate, error) {
+	code, err := metricCode(m)
+	if err != nil {
+		return nil, err
+	}
+	var blob []byte
+	offs := []C.uint64_t{0}
+	for _, q := range queries {
+		blob = append(blob, q...)
+		offs = append(offs, C.uint64_t(len(blob)))
+	}
+	n := len(queries)
+	ids := make([]C.uint32_t, n*k)
+	scores := make([]C.double, n*k)
+	counts := make([]C.uint32_t, n)
+	var bp *C.uint8_t
+	if len(blob) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
+	}
+	C.sg_index_retain(i.h) // the handle stays valid while this query is in flight (service.go:85-88 swaps indexes)
+	rc := C.sg_suggest_batch(i.h, bp, &offs[0], C.uint32_t(n), code, C.double(similarity), C.uint32_t(k), &ids[0], &scores[0], &counts[0])
+	C.sg_index_release(i.h)
+	runtime.KeepAlive(i)
+	if rc != 0 {
+		return nil, lastError(rc)
+	}
+	out := make([][]suggest.Candidate, n)
+	for q := 0; q < n; q++ {
+		c := uint32(counts[q])
+		switch c {
+		case C.SG_COUNT_REF_PANIC:
+			panic("makechan: size out of range") // what pkg/suggest/suggester.go:62 does on this query
+		case C.SG_COUNT_REF_DEADLOCK, C.SG_COUNT_TOO_LONG:
+			return nil, fmt.Errorf("suggesthip: query %d cannot be answered (status %#x)", q, c)
+		}
+		out[q] = make([]suggest.Candidate, c)
+		for j := uint32(0); j < c; j++ {
+			out[q][j] = suggest.Candidate{Key: uint32(ids[q*k+int(j)]), Score: float64(scores[q*k+int(j)])}
+		}
+	}
+	return out, nil
+}
+
+// Autocomplete implements suggest.Autocomplete (pkg/suggest/autocomplete.go:14-17).
+func (i *Index) Autocomplete(query string, factory suggest.CollectorManagerFactory) ([]suggest.Candidate, error) {
+	limit := topK(factory)
+	blob := []byte(query)
+	offs := []C.uint64_t{0, C.uint64_t(len(blob))}
+	ids := make([]C.uint32_t, limit)
+	var cnt C.uint32_t
+	var bp *C.uint8_t
+	if len(blob) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
+	}
+	if rc := C.sg_autocomplete_batch(i.h, bp, &offs[0], 1, C.uint32_t(limit), &ids[0], &cnt); rc != 0 {
+		return nil, lastError(rc)
+	}
+	runtime.KeepAlive(i)
+	out := make([]suggest.Candidate, uint32(cnt))
+	for j := range out {
+		out[j] = suggest.Candidate{Key: uint32(ids[j]), Score: -float64(ids[j])} // collector.go:104-106
+	}
+	return out, nil
+}
