@@ -891,7 +891,7 @@ struct sg_index {
   DeviceIndex dix{};
   std::vector<void*> allocs;
   uint64_t device_bytes = 0;
-  uint32_t log2_cnt = 10;
+  uint32_t log2_cnt = 11;
 };
 
 #define HIP_TRY(expr)                                                                   \
