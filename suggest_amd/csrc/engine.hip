@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -28,7 +29,8 @@ namespace sg {
 #define SG_CAND_CAP 64
 #define SG_K_LDS 64
 #define SG_WRAP_MAX 8
-#define SG_ROWS_CAP 1024   // u32 entries of seg_off rows kept in LDS per tile
+#define SG_ROWS_CAP 768    // u32 entries of seg_off rows kept in LDS per tile
+#define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
 #define SG_T_FLOOR 8       // lowest flag threshold list skipping may leave
@@ -44,6 +46,15 @@ struct DeviceIndex {
   const uint8_t* na_alpha;
   const uint32_t* lower_from;
   const uint32_t* lower_to;
+  // documents that repeat a term: null / 0 when the dictionary has none
+  const uint32_t* dup_ts;      // [n_dups] term*S+segment, ascending (then by doc)
+  const uint32_t* dup_doc;     // [n_dups]
+  const uint32_t* dup_mult;    // [n_dups] occurrences of the term in the doc (>= 2)
+  const uint32_t* dup_docs;    // [n_dup_docs] ascending docIDs with any repeated term
+  const uint32_t* extra_ts;    // [n_extra] term*S+segment of lists holding repeats, ascending
+  const uint32_t* extra_cnt;   // [n_extra] raw length - stored length of that list
+  const uint32_t* list_len;    // [n_terms*S] stored (de-duplicated) list lengths
+  uint32_t n_dups, n_dup_docs, n_extra;
   uint32_t slot_mask, n_na, n_lower;
   uint32_t S, n_terms, q, n_docs;
   uint32_t wrap0[SG_WRAP_MAX], wrap1[SG_WRAP_MAX];
@@ -296,6 +307,177 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
   return v;
 }
 
+// Go 1.14 sort.Sort (quickSort with ninther pivot, heapSort fallback, ShellSort pass + insertionSort below
+// 13 elements) on (key,val) pairs in LDS ordered by key, restated from the published algorithm of the Go
+// standard library the reference builds with (golang:1.14.4).  It decides the order of EQUAL-length posting
+// lists in cpMerge.Merge (cp_merge.go:24) / Intersect (list_intersector.go:30), which only matters for
+// documents that repeat a term.  Executed uniformly by the whole wave (rare path).
+struct PairSort {
+  uint32_t* k; uint32_t* v; int* stk;
+  __device__ bool less(int i, int j) const { return k[i] < k[j]; }
+  __device__ void swap(int i, int j) { uint32_t t = k[i]; k[i] = k[j]; k[j] = t; t = v[i]; v[i] = v[j]; v[j] = t; }
+  __device__ void insertion(int a, int b) {
+    for (int i = a + 1; i < b; i++) for (int j = i; j > a && less(j, j - 1); j--) swap(j, j - 1);
+  }
+  __device__ void sift_down(int lo, int hi, int first) {
+    int root = lo;
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= hi) return;
+      if (child + 1 < hi && less(first + child, first + child + 1)) child++;
+      if (!less(first + root, first + child)) return;
+      swap(first + root, first + child);
+      root = child;
+    }
+  }
+  __device__ void heap_sort(int a, int b) {
+    const int first = a, hi = b - a;
+    for (int i = (hi - 1) / 2; i >= 0; i--) sift_down(i, hi, first);
+    for (int i = hi - 1; i >= 0; i--) { swap(first, first + i); sift_down(0, i, first); }
+  }
+  __device__ void median3(int m1, int m0, int m2) {
+    if (less(m1, m0)) swap(m1, m0);
+    if (less(m2, m1)) { swap(m2, m1); if (less(m1, m0)) swap(m1, m0); }
+  }
+  __device__ void do_pivot(int lo, int hi, int* midlo, int* midhi) {
+    const int m = (int)((unsigned)(lo + hi) >> 1);
+    if (hi - lo > 40) {
+      const int s = (hi - lo) / 8;
+      median3(lo, lo + s, lo + 2 * s);
+      median3(m, m - s, m + s);
+      median3(hi - 1, hi - 1 - s, hi - 1 - 2 * s);
+    }
+    median3(lo, m, hi - 1);
+    const int pivot = lo;
+    int a = lo + 1, c = hi - 1;
+    for (; a < c && less(a, pivot); a++) {}
+    int b = a;
+    for (;;) {
+      for (; b < c && !less(pivot, b); b++) {}
+      for (; b < c && less(pivot, c - 1); c--) {}
+      if (b >= c) break;
+      swap(b, c - 1); b++; c--;
+    }
+    bool protect = hi - c < 5;
+    if (!protect && hi - c < (hi - lo) / 4) {
+      int dups = 0;
+      if (!less(pivot, hi - 1)) { swap(c, hi - 1); c++; dups++; }
+      if (!less(b - 1, pivot)) { b--; dups++; }
+      if (!less(m, pivot)) { swap(m, b - 1); b--; dups++; }
+      protect = dups > 1;
+    }
+    if (protect) {
+      for (;;) {
+        for (; a < b && !less(b - 1, pivot); b--) {}
+        for (; a < b && less(a, pivot); a++) {}
+        if (a >= b) break;
+        swap(a, b - 1); a++; b--;
+      }
+    }
+    swap(pivot, b - 1);
+    *midlo = b - 1; *midhi = c;
+  }
+  __device__ void sort(int n) {
+    int depth = 0;
+    for (int i = n; i > 0; i >>= 1) depth++;
+    depth *= 2;
+    int sp = 0;
+    stk[0] = 0; stk[1] = n; stk[2] = depth; sp = 1;
+    while (sp > 0) {
+      sp--;
+      int a = stk[sp * 3], b = stk[sp * 3 + 1], d = stk[sp * 3 + 2];
+      while (b - a > 12) {
+        if (d == 0) { heap_sort(a, b); a = b; break; }
+        d--;
+        int mlo, mhi;
+        do_pivot(a, b, &mlo, &mhi);
+        if (mlo - a < b - mhi) { stk[sp * 3] = a; stk[sp * 3 + 1] = mlo; stk[sp * 3 + 2] = d; sp++; a = mhi; }
+        else { stk[sp * 3] = mhi; stk[sp * 3 + 1] = b; stk[sp * 3 + 2] = d; sp++; b = mlo; }
+      }
+      if (b - a > 1) {
+        for (int i = a + 6; i < b; i++) if (less(i, i - 6)) swap(i, i - 6);
+        insertion(a, b);
+      }
+    }
+  }
+};
+
+__device__ uint32_t d_lower_bound_u32(const uint32_t* p, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// Secondary entries of a doc that repeats a term (reference quirk): cpMerge keeps one
+// candidate per COPY of the doc in the n-T+1 shortest lists (cp_merge.go:47-78); copy j >= 2 ends with
+// overlap #{merged lists holding >= j copies} + #{probed lists holding the doc} and is collected if that
+// reaches T; the intersector (n == T) collects the doc once per copy in the shortest list
+// (list_intersector.go:37-70).  fm0/fm1 = query terms (lanes, round 0/1) whose list in the doc's segment
+// holds it.  Writes the extra overlaps to scratch[2*SG_MAX_A+64 ..] and returns their number; `scratch` is its
+// own LDS region (the counters may be live: the overflow pass emits while it still reads them).
+// (A real call would cost the kernel ~100 VGPRs: kept inline.)
+__device__ __forceinline__ int dup_secondary_overlaps(const DeviceIndex& ix, const uint32_t* term, const uint32_t* rows,
+                                                   uint32_t* scratch, int A, uint32_t stride, int w, uint32_t B, int T,
+                                                   uint32_t d, uint64_t fm0, uint64_t fm1, int lane) {
+  const uint32_t S32 = ix.S;
+  uint32_t* sk = scratch;
+  uint32_t* sv = scratch + SG_MAX_A;
+  int* stk = (int*)(scratch + 2 * SG_MAX_A);
+  uint32_t* extra = scratch + 2 * SG_MAX_A + 64;
+  const int a_rounds = (A + 63) >> 6;
+  int n = 0;
+  for (int r = 0; r < a_rounds; r++) {
+    const int i = r * 64 + lane;
+    bool present = false;
+    uint32_t len = 0, mult = 0;
+    if (i < A) {
+      const uint32_t t = term[i];
+      present = t != kNoTerm && rows[i * stride + w + 1] != rows[i * stride + w];
+      if (present) {
+        const uint32_t ts = t * S32 + B;
+        len = ix.list_len[ts];                          // stored (de-duplicated) length
+        const uint32_t e = d_lower_bound_u32(ix.extra_ts, ix.n_extra, ts);
+        const uint32_t raw = len + ((e < ix.n_extra && ix.extra_ts[e] == ts) ? ix.extra_cnt[e] : 0u);
+        const bool has = ((r ? fm1 : fm0) >> lane) & 1ull;
+        mult = has ? 1u : 0u;
+        if (raw <= 256u) {                              // VB / skip lists keep repeats; roaring (> 256) drops them
+          len = raw;
+          if (has) {
+            uint32_t lo = d_lower_bound_u32(ix.dup_ts, ix.n_dups, ts);
+            while (lo < ix.n_dups && ix.dup_ts[lo] == ts && ix.dup_doc[lo] < d) lo++;
+            if (lo < ix.n_dups && ix.dup_ts[lo] == ts && ix.dup_doc[lo] == d) mult = ix.dup_mult[lo];
+          }
+        }
+      }
+    }
+    const uint64_t pm = ballot(present);
+    const int pos = n + (int)popc64(pm & ((1ull << lane) - 1ull));
+    if (present) { sk[pos] = len; sv[pos] = mult; }
+    n += (int)popc64(pm);
+  }
+  __syncthreads();
+  PairSort ps{sk, sv, stk};
+  ps.sort(n);                                           // sort.Sort(rid) by Len
+  __syncthreads();
+  int n_extra = 0;
+  if (n == T) {                                         // intersector: once per copy in the shortest list
+    const int copies = (int)sv[0];
+    for (int c = 1; c < copies && n_extra < 64; c++) extra[n_extra++] = (uint32_t)n;
+  } else {
+    const int min_q = n - T + 1;
+    uint32_t maxm = 0;
+    int tail = 0;
+    for (int p = 0; p < n; p++) { if (p < min_q) maxm = max(maxm, sv[p]); else tail += sv[p] ? 1 : 0; }
+    for (uint32_t j = 2; j <= maxm && n_extra < 64; j++) {
+      int c = tail;
+      for (int p = 0; p < min_q; p++) c += sv[p] >= j ? 1 : 0;
+      if (c >= T) extra[n_extra++] = (uint32_t)c;
+    }
+  }
+  __syncthreads();
+  return n_extra;
+}
+
 struct TopK {  // wave-uniform state; arrays live in LDS (k <= SG_K_LDS) or in the query's output row
   uint64_t* s;
   uint32_t* id;
@@ -429,7 +611,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* rows = term + SG_MAX_A;
   uint32_t* cand = rows + SG_ROWS_CAP;
   uint32_t* candw = cand + SG_CAND_CAP;             // segment (within the tile) of each queued candidate
-  uint32_t* tk_id_lds = candw + SG_CAND_CAP;
+  uint32_t* dup_scratch = candw + SG_CAND_CAP + 32; // 32 words of verdict staging behind the queue, then this
+  uint32_t* tk_id_lds = dup_scratch + SG_DUP_SCRATCH;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
@@ -507,12 +690,26 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     // ---- candidate queue of the tile: docs whose bucket reached the flag threshold wait here and are
     //      verified together (their binary searches overlap in flight) instead of stalling the stream ----
     uint32_t qn = 0;
-    auto emit = [&](uint32_t d, int overlap, int w) {
+    auto offer = [&](uint32_t d, int overlap, int w) {
+      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
+      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
+    };
+    auto emit_secondaries = [&](uint32_t d, int w, int T, uint64_t fm0, uint64_t fm1) {
+      __syncthreads();
+      const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T, d, fm0, fm1, lane);
+      const uint32_t* extra = dup_scratch + 2 * SG_MAX_A + 64;
+      for (int x = 0; x < n_extra; x++) offer(d, (int)extra[x], w);
+      __syncthreads();
+    };
+    auto emit = [&](uint32_t d, int overlap, int w, uint64_t fm0, uint64_t fm1) {
       const int T = (int)readlane((uint32_t)seg_T, w);
       if (overlap < T) return;
       DBG_COUNT(5, 1)
-      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
-      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
+      offer(d, overlap, w);
+      if (ix.n_dup_docs) {                                  // dictionaries whose docs never repeat a term skip this
+        const uint32_t p = d_lower_bound_u32(ix.dup_docs, ix.n_dup_docs, d);
+        if (p < ix.n_dup_docs && ix.dup_docs[p] == d) emit_secondaries(d, w, T, fm0, fm1);
+      }
     };
     auto flush_queue = [&]() {
       __syncthreads();
@@ -521,6 +718,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         uint32_t qd[4], qw[4];
         bool ok[4];
         int ov[4] = {0, 0, 0, 0};
+        uint64_t fmask[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
         for (int j = 0; j < 4; j++) { ok[j] = c0 + j < qn; qd[j] = ok[j] ? cand[c0 + j] : 0u; qw[j] = ok[j] ? candw[c0 + j] : 0u; }
         for (int r = 0; r < a_rounds; r++) {
@@ -552,11 +750,28 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const bool found = lo[j] < n4[j] && pp[j][lo[j]] == qd[j];
-            ov[j] += (int)popc64(ballot(found));
+            const uint64_t fmj = ballot(found);
+            ov[j] += (int)popc64(fmj);
+            if (r == 0) fmask[j][0] = fmj; else fmask[j][1] = fmj;
           }
         }
+        // stage the four verdicts in LDS (queue slots are consumed) so that emit() is instantiated once
+        __syncthreads();
+        if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (ok[j]) emit(qd[j], ov[j], (int)qw[j]);
+          for (int j = 0; j < 4; j++) {
+            uint32_t* st = candw + SG_CAND_CAP + j * 8;           // staging area behind the queue
+            st[0] = qd[j]; st[1] = (uint32_t)ov[j]; st[2] = qw[j]; st[3] = ok[j] ? 1u : 0u;
+            st[4] = (uint32_t)fmask[j][0]; st[5] = (uint32_t)(fmask[j][0] >> 32);
+            st[6] = (uint32_t)fmask[j][1]; st[7] = (uint32_t)(fmask[j][1] >> 32);
+          }
+        }
+        __syncthreads();
+#pragma nounroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t* st = candw + SG_CAND_CAP + j * 8;
+          if (st[3]) emit(st[0], (int)st[1], (int)st[2], (uint64_t)st[4] | ((uint64_t)st[5] << 32), (uint64_t)st[6] | ((uint64_t)st[7] << 32));
+        }
       }
       qn = 0;
     };
@@ -650,7 +865,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
 
       // exact overlap of doc d, found in list jj at chunk `chunk` of the posting store: locate its
       // segment, then count the query-term occurrences whose list in that segment contains d
-      auto verify = [&](uint32_t d, uint32_t jj, uint32_t chunk, int* seg_w, int* last_list) -> int {
+      auto verify = [&](uint32_t d, uint32_t jj, uint32_t chunk, int* seg_w, int* last_list, uint64_t (&fm)[2]) -> int {
+        fm[0] = fm[1] = 0;
         int w = g0;
         while (w < g1 && rows[jj * stride + w + 1] <= chunk) w++;
         *seg_w = w;
@@ -669,6 +885,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           }
           const uint64_t m = ballot(found);
           c += (int)popc64(m);
+          if (r == 0) fm[0] = m; else fm[1] = m;
           if (m) last = r * 64 + 63 - __builtin_clzll(m);
         }
         *last_list = last;
@@ -841,8 +1058,9 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
                 const uint32_t dd = readlane(d, l);
                 if (in_cand(dd)) continue;
                 int w, last;
-                const int ov = verify(dd, (uint32_t)i, s + c0 + (uint32_t)l, &w, &last);
-                if (last == i && dd >= lo_doc && dd < hi_doc) emit(dd, ov, w);
+                uint64_t fm[2];
+                const int ov = verify(dd, (uint32_t)i, s + c0 + (uint32_t)l, &w, &last, fm);
+                if (last == i && dd >= lo_doc && dd < hi_doc) emit(dd, ov, w, fm[0], fm[1]);
               }
             }
           }
@@ -925,7 +1143,7 @@ const LowerPair kLowerPairs[] = {
 };
 
 size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + SG_K_LDS + SG_K_LDS * 2;
+  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
@@ -1015,6 +1233,25 @@ int sg_index_upload(sg_index* ix, int device) {
   for (const auto& p : kLowerPairs) { lf.push_back(p.from); lt.push_back(p.to); }
   if ((rc = to_device(ix, lf.data(), lf.size(), &d.lower_from))) return rc;
   if ((rc = to_device(ix, lt.data(), lt.size(), &d.lower_to))) return rc;
+  if (!h.dups.empty()) {   // documents that repeat a term: side tables for the secondary-entry path
+    const uint32_t S32 = h.n_segments;
+    std::vector<uint32_t> dts, ddoc, dmult, ddocs, ets, ecnt;
+    for (const auto& e : h.dups) {
+      const uint32_t ts = e.term * S32 + e.segment;
+      dts.push_back(ts); ddoc.push_back(e.doc); dmult.push_back(e.mult); ddocs.push_back(e.doc);
+      if (!ets.empty() && ets.back() == ts) ecnt.back() += e.mult - 1; else { ets.push_back(ts); ecnt.push_back(e.mult - 1); }
+    }
+    std::sort(ddocs.begin(), ddocs.end());
+    ddocs.erase(std::unique(ddocs.begin(), ddocs.end()), ddocs.end());
+    if ((rc = to_device(ix, dts.data(), dts.size(), &d.dup_ts))) return rc;
+    if ((rc = to_device(ix, ddoc.data(), ddoc.size(), &d.dup_doc))) return rc;
+    if ((rc = to_device(ix, dmult.data(), dmult.size(), &d.dup_mult))) return rc;
+    if ((rc = to_device(ix, ddocs.data(), ddocs.size(), &d.dup_docs))) return rc;
+    if ((rc = to_device(ix, ets.data(), ets.size(), &d.extra_ts))) return rc;
+    if ((rc = to_device(ix, ecnt.data(), ecnt.size(), &d.extra_cnt))) return rc;
+    if ((rc = to_device(ix, h.list_len.data(), h.list_len.size(), &d.list_len))) return rc;
+    d.n_dups = (uint32_t)dts.size(); d.n_dup_docs = (uint32_t)ddocs.size(); d.n_extra = (uint32_t)ets.size();
+  }
   d.slot_mask = (uint32_t)h.slots.size() - 1;
   d.n_na = (uint32_t)h.sym.na_rune.size();
   d.n_lower = (uint32_t)lf.size();

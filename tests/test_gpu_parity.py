@@ -112,33 +112,35 @@ def test_service_cars_golden(reference_tests, cars_lines):
         assert [r.value for r in res] == exp, q
 
 
-def _no_dup_docs(ora_index, lines):
-    """docIDs of documents that repeat a term (secondary CPMerge entries)"""
-    dup = set()
-    for i, l in enumerate(lines):
-        t = ora_index.tokenize(l)
-        if len(set(t)) != len(t):
-            dup.add(i)
-    return dup
-
-
 def test_cars_all_lines_as_queries(cars_lines):
-    """Every dictionary line (and an edited copy) as a query, several metrics.  Until the duplicate-term
-    path lands, rows whose oracle result contains a doc twice are compared on their primary entries."""
+    """Every third dictionary line (and edited copies) as a query, several metrics, ALL rows compared — including
+    the rows where the reference returns a document twice (documents that repeat a term)."""
     from suggest_amd import NGramIndex
     gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
     ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
     queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]] + [l.lower()[:-2] for l in cars_lines[::11]]
     qb, qo = oracle.pack_strings(queries)
-    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.5, 10), ("dice", 0.6, 3)]:
+    n_dup_rows = 0
+    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.5, 10), ("dice", 0.6, 3), ("cosine", 0.3, 40), ("jaccard", 0.2, 100)]:
         g = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k)
         o = ora.suggest_batch(qb, qo, metric, alpha, k)
-        oi, oc = o[0], o[2]
-        clean = np.array([len(set(oi[i, :oc[i]].tolist())) == oc[i] for i in range(len(queries))])
-        ids, sc, cnt = g
-        sel = np.nonzero(clean)[0]
-        assert sel.size > 0.8 * len(queries)
-        assert_same((ids[sel], sc[sel], cnt[sel]), (o[0][sel], o[1][sel], o[2][sel]), [queries[i] for i in sel])
+        n_dup_rows += sum(len(set(o[0][i, :o[2][i]].tolist())) != o[2][i] for i in range(len(queries)))
+        assert_same(g, o, queries)
+    assert n_dup_rows > 50          # the quirk is really exercised
+
+
+def test_cars_autocomplete_with_repeated_terms(cars_lines):
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    queries = [l[:n] for l in cars_lines[::9] for n in (3, 6, 12)] + [b"NISSAN TITAN", b"TITAN", b"AN "]
+    qb, qo = oracle.pack_strings(queries)
+    for limit in (3, 20):
+        ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=limit)
+        oi, oc, _ = ora.autocomplete_batch(qb, qo, limit)
+        assert np.array_equal(cnt, oc)
+        valid = np.arange(limit)[None, :] < cnt[:, None]
+        assert np.array_equal(ids[valid], oi[valid])
 
 
 def test_words_parity(words_lines, reference_tests):
@@ -181,5 +183,4 @@ def test_edge_queries(cars_lines):
     oi, os_, oc, _ = ora.suggest_batch(qb, qo, "jaccard", 0.5, 5)
     assert np.array_equal(cnt, oc), (cnt, oc)
     assert cnt[0] == 0 and cnt[9] == 0xFFFFFFFF          # empty -> no result; overlong -> reference panics
-    clean = [i for i in range(len(queries)) if oc[i] < 0xFFFFFFF0 and len(set(oi[i, :oc[i]].tolist())) == oc[i]]
-    assert_same((ids[clean], sc[clean], cnt[clean]), (oi[clean], os_[clean], oc[clean]))
+    assert_same((ids, sc, cnt), (oi, os_, oc))
