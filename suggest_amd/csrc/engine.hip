@@ -532,23 +532,38 @@ static_assert(SG_UNROLL == 4, "u32x16 below holds 4 rows x 4 postings");
 // u32 counter per word), issued back to back and waited for once.  live[u] is 1 for lanes inside
 // the list, 0 for lanes past its end (they re-read the list's last chunk and add 0).  Returns the
 // ballot of lanes holding a posting whose bucket reached T; `was` receives the counts seen.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// LDS byte address of the counter word of doc d.  amask selects the bucket bits of the docID and is
+// already a byte mask, cbase is the LDS address of the counter array, so the address is ONE v_and_or_b32:
+//   u32 counters: bucket = docID bits [2, lg+2)   -> amask = ((1<<lg)-1) << 2
+//   u8  counters: bucket = docID bits [0, lg), four per word -> amask = ((1<<lg)-1) & ~3, byte lane = d & 3
+__device__ __forceinline__ lds_u32* counter_word(uint32_t d, uint32_t amask, uint32_t cbase) {
+  return (lds_u32*)(uintptr_t)((d & amask) | cbase);
+}
+
 template <bool U8>
-__device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], uint32_t* cnt,
-                                               uint32_t bmask, uint32_t Tm1, u32x16& was) {
+__device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], uint32_t amask,
+                                               uint32_t cbase, uint32_t dummy, uint32_t Tm1, u32x16& was) {
   uint32_t old[4 * SG_UNROLL];
   uint32_t shf[U8 ? 4 * SG_UNROLL : 1];
 #pragma unroll
   for (int u = 0; u < SG_UNROLL; u++) {
     const uint32_t dv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+    // Lanes past the end of the list hold copies of its last chunk; aimed at the real counters they would
+    // all hit the same four words (address conflicts serialise LDS atomics).  They add 0 to a lane-private
+    // dummy word instead: per ROW two selects, per posting still one v_and_or_b32.
+    const uint32_t am = live[u] ? amask : 0u;
+    const uint32_t cb = live[u] ? cbase : dummy;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
+      lds_u32* w = counter_word(dv[e], am, cb);
       if (U8) {
-        const uint32_t b = dv[e] & bmask;
-        const uint32_t sh = (b & 3u) << 3;
+        const uint32_t sh = (dv[e] & 3u) << 3;
         shf[u * 4 + e] = sh;
-        old[u * 4 + e] = atomicAdd(&cnt[b >> 2], live[u] << sh);
+        old[u * 4 + e] = __hip_atomic_fetch_add(w, live[u] << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
-        old[u * 4 + e] = atomicAdd(&cnt[dv[e] & bmask], live[u]);
+        old[u * 4 + e] = __hip_atomic_fetch_add(w, live[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
@@ -606,12 +621,15 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   const uint32_t qi = blockIdx.x;
   const DeviceIndex& ix = a.ix;
   const uint32_t cnt_words = 1u << a.log2_cnt;
-  uint32_t* cnt = smem;                              // LDS address 0: counter index == ds offset
+  uint32_t* cnt = smem;
+  const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32*)cnt;   // LDS byte address of the counters (aligned to their size)
   uint32_t* term = cnt + cnt_words;
   uint32_t* rows = term + SG_MAX_A;
   uint32_t* cand = rows + SG_ROWS_CAP;
   uint32_t* candw = cand + SG_CAND_CAP;             // segment (within the tile) of each queued candidate
-  uint32_t* dup_scratch = candw + SG_CAND_CAP + 32; // 32 words of verdict staging behind the queue, then this
+  uint32_t* dummy_w = candw + SG_CAND_CAP + 32;     // 32 words of verdict staging behind the queue, then one
+  const uint32_t dummy_lane = (uint32_t)(uintptr_t)(lds_u32*)(dummy_w + lane);   // private dummy counter word per lane
+  uint32_t* dup_scratch = dummy_w + 64;
   uint32_t* tk_id_lds = dup_scratch + SG_DUP_SCRATCH;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
@@ -898,7 +916,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       };
       auto on_flag = [&](uint32_t dd, uint32_t jj, uint32_t chunk) {   // dd flagged in list jj at posting-store chunk
         if (u8) {                                              // a saturating u8 counter would carry into its neighbour
-          const uint32_t b = dd & ((1u << lg) - 1u);
+          const uint32_t b = dd & ((1u << lg) - 1u);       // u8 bucket = low lg bits of the docID
           if (((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) >= 250u) saturated = true;
         }
         if (in_cand(dd)) return;
@@ -910,24 +928,27 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         DBG_COUNT(3, 1)
         __syncthreads();
       };
-      // slow path of one counted batch: rows u = 0..3 hold list jl[u] from chunk cb[u] on
+      // slow path of one counted batch: rows u = 0..3 hold list jl[u] from chunk cb[u] on; visits only the
+      // flagged postings (per-lane bit mask, then uniform dynamic indexing of the register vectors)
       auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
                          const uint32_t (&jl)[SG_UNROLL], const uint32_t (&cb)[SG_UNROLL], uint32_t Tm1) {
         const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
                            v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
-        const uint32_t __attribute__((ext_vector_type(4))) lv = {live[0], live[1], live[2], live[3]};
         const uint32_t __attribute__((ext_vector_type(4))) jv = {jl[0], jl[1], jl[2], jl[3]};
         const uint32_t __attribute__((ext_vector_type(4))) cv = {cb[0], cb[1], cb[2], cb[3]};
-#pragma nounroll
-        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {            // uniform dynamic index into the register vectors
-          uint64_t m = ballot(lv[ue >> 2] && was[ue] >= Tm1);
-          const uint32_t dsel = vv[ue];
-          const uint32_t jj = jv[ue >> 2], c0 = cv[ue >> 2];
-          while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
+        uint32_t fl = 0;
+#pragma unroll
+        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) fl |= ((live[ue >> 2] && was[ue] >= Tm1) ? 1u : 0u) << ue;
+        uint64_t lanes = ballot(fl != 0);
+        while (lanes) {
+          const int l = __builtin_ctzll(lanes);
+          lanes &= lanes - 1;
+          uint32_t f = readlane(fl, l);
+          while (f) {
+            const int ue = __builtin_ctz(f);
+            f &= f - 1;
             DBG_COUNT(2, 1)
-            on_flag(readlane(dsel, l), jj, c0 + (uint32_t)l);
+            on_flag(readlane(vv[ue], l), jv[ue >> 2], cv[ue >> 2] + (uint32_t)l);
           }
         }
       };
@@ -967,45 +988,56 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
         for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
-        const uint32_t bmask = (1u << lg) - 1u, Tm1 = (uint32_t)Teff - 1u;
+        const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
-        // Row iterator (wave-uniform state): rows of 64 chunks, list after list, SG_UNROLL rows per
-        // batch across list boundaries; the next batch's loads are issued before the current one is counted.
-        uint64_t todo0 = ballot(ln_r[0] != 0) & ~skip_m[0], todo1 = a_rounds > 1 ? ballot(ln_r[1] != 0) & ~skip_m[1] : 0ull;
-        uint32_t cur_s = 0, cur_n = 0, cur_c0 = 0, cur_j = 0;
+        // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the
+        // running row number where they start (pr, wave scan); row R belongs to the one lane with
+        // pr <= R < pr+nr, found by a ballot — no scalar branching, no LDS.
+        uint32_t nr[2], pr[2];
+        uint32_t n_rows = 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const bool skipped = (skip_m[r] >> lane) & 1ull;
+          nr[r] = (r < a_rounds && !skipped) ? (ln_r[r] + 63u) >> 6 : 0u;
+          const uint32_t incl = wave_scan_incl(nr[r], lane);
+          pr[r] = n_rows + incl - nr[r];
+          n_rows += readlane(incl, 63);
+        }
+        uint32_t next_row = 0;
         uint4 v[SG_UNROLL], vn[SG_UNROLL];
         uint32_t live[SG_UNROLL], liven[SG_UNROLL], jl[SG_UNROLL], jln[SG_UNROLL], cb[SG_UNROLL], cbn[SG_UNROLL];
         u32x16 was;
         auto fetch = [&](uint4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL], uint32_t (&jj)[SG_UNROLL], uint32_t (&cc)[SG_UNROLL]) {
 #pragma unroll
           for (int u = 0; u < SG_UNROLL; u++) {
-            if (cur_c0 >= cur_n) {                              // next non-empty list
-              if (todo0) {
-                const int li = __builtin_ctzll(todo0);
-                todo0 &= todo0 - 1;
-                cur_s = readlane(ls_r[0], li); cur_n = readlane(ln_r[0], li); cur_j = (uint32_t)li; cur_c0 = 0;
-              } else if (todo1) {
-                const int li = __builtin_ctzll(todo1);
-                todo1 &= todo1 - 1;
-                cur_s = readlane(ls_r[1], li); cur_n = readlane(ln_r[1], li); cur_j = 64u + (uint32_t)li; cur_c0 = 0;
-              } else { cur_n = 0; cur_c0 = 0; }                 // no rows left: dead row (adds 0)
+            const uint32_t R = next_row + (uint32_t)u;
+            uint32_t s_, n_, p_, j_;
+            const uint64_t m0 = ballot(R - pr[0] < nr[0]);
+            if (m0 || a_rounds == 1) {
+              const int li = m0 ? __builtin_ctzll(m0) : 0;
+              s_ = readlane(ls_r[0], li); n_ = m0 ? readlane(ln_r[0], li) : 0u; p_ = readlane(pr[0], li); j_ = (uint32_t)li;
+            } else {
+              const uint64_t m1 = ballot(R - pr[1] < nr[1]);
+              const int li = m1 ? __builtin_ctzll(m1) : 0;
+              s_ = readlane(ls_r[1], li); n_ = m1 ? readlane(ln_r[1], li) : 0u; p_ = readlane(pr[1], li); j_ = 64u + (uint32_t)li;
             }
-            const uint32_t c = cur_c0 + (uint32_t)lane;
-            lv[u] = c < cur_n ? 1u : 0u;
-            jj[u] = cur_j;
-            cc[u] = cur_s + cur_c0;
-            vv[u] = post4[cur_s + min(c, cur_n ? cur_n - 1 : 0u)];
-            cur_c0 += 64;
+            const uint32_t c0 = n_ ? (R - p_) << 6 : 0u;       // dead row (past the last): n_ = 0, adds nothing
+            const uint32_t c = c0 + (uint32_t)lane;
+            lv[u] = c < n_ ? 1u : 0u;
+            jj[u] = j_;
+            cc[u] = s_ + c0;
+            vv[u] = post4[s_ + min(c, n_ ? n_ - 1 : 0u)];
           }
+          next_row += SG_UNROLL;
         };
         // ping-pong between two register sets: the next batch's loads are in flight while one is counted
-        auto rows_left = [&]() -> bool { return (todo0 | todo1) != 0 || cur_c0 < cur_n; };
+        auto rows_left = [&]() -> bool { return next_row < n_rows; };
         auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], const uint32_t (&pj)[SG_UNROLL],
                            const uint32_t (&pc)[SG_UNROLL]) {
           uint64_t any = 0;
           if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
-          else any = u8 ? count_rows<true>(pv, pl, cnt, bmask, Tm1, was) : count_rows<false>(pv, pl, cnt, bmask, Tm1, was);
+          else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
           DBG_COUNT(1, 1)
           if (any) { PH(5) flagged(pv, pl, was, pj, pc, Tm1); PH(6) }
         };
@@ -1048,7 +1080,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
               bool flag = false;
               if (c < n && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
                 const uint32_t b = d & ((1u << lg) - 1u);
-                const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[b];
+                const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
                 flag = now >= (uint32_t)Teff;
               }
               uint64_t m = ballot(flag);
@@ -1143,7 +1175,7 @@ const LowerPair kLowerPairs[] = {
 };
 
 size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
+  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 64 + SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
