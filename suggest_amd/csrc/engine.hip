@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -991,6 +992,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
+        auto stream_rows = [&](auto two_tag) {
+        constexpr bool TWO = decltype(two_tag)::value;
         // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the
         // running row number where they start (pr, wave scan); row R belongs to the one lane with
         // pr <= R < pr+nr, found by a ballot — no scalar branching, no LDS.
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
             const uint32_t R = next_row + (uint32_t)u;
             uint32_t s_, n_, p_, j_;
             const uint64_t m0 = ballot(R - pr[0] < nr[0]);
-            if (m0 || a_rounds == 1) {
+            if (!TWO || m0) {                                   // (compile-time true for queries of <= 64 terms: straight-line code)
               const int li = m0 ? __builtin_ctzll(m0) : 0;
               s_ = readlane(ls_r[0], li); n_ = m0 ? readlane(ln_r[0], li) : 0u; p_ = readlane(pr[0], li); j_ = (uint32_t)li;
             } else {
@@ -1032,7 +1035,6 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           next_row += SG_UNROLL;
         };
         // ping-pong between two register sets: the next batch's loads are in flight while one is counted
-        auto rows_left = [&]() -> bool { return next_row < n_rows; };
         auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], const uint32_t (&pj)[SG_UNROLL],
                            const uint32_t (&pc)[SG_UNROLL]) {
           uint64_t any = 0;
@@ -1041,18 +1043,19 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           DBG_COUNT(1, 1)
           if (any) { PH(5) flagged(pv, pl, was, pj, pc, Tm1); PH(6) }
         };
-        bool have = rows_left();
-        if (have) fetch(v, live, jl, cb);
-        while (have) {
-          bool more = rows_left();
-          if (more) fetch(vn, liven, jln, cbn);
+        // fetches are unconditional (rows past the last are dead rows) so that the compiler can count the
+        // loads in flight: process(v) waits for v's four loads only (vmcnt(4)), not for the prefetched batch
+        const uint32_t n_batches = (n_rows + SG_UNROLL - 1) / SG_UNROLL;
+        fetch(v, live, jl, cb);
+        for (uint32_t bi = 0; bi < n_batches; bi += 2) {
+          fetch(vn, liven, jln, cbn);
           process(v, live, jl, cb);
-          if (!more) break;
-          more = rows_left();
-          if (more) fetch(v, live, jl, cb);
+          if (bi + 1 >= n_batches) break;
+          fetch(v, live, jl, cb);
           process(vn, liven, jln, cbn);
-          have = more;
         }
+        };
+        if (a_rounds > 1) stream_rows(std::true_type{}); else stream_rows(std::false_type{});
         PH(5)
         if (!(u8 && saturated)) break;
         // re-run with u32 counters: candidates already verified stay in the dedup set (emitted once)
@@ -1141,7 +1144,7 @@ struct sg_index {
   DeviceIndex dix{};
   std::vector<void*> allocs;
   uint64_t device_bytes = 0;
-  uint32_t log2_cnt = 11;
+  uint32_t log2_cnt = 10;
 };
 
 #define HIP_TRY(expr)                                                                   \
