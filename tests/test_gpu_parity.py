@@ -184,3 +184,60 @@ def test_edge_queries(cars_lines):
     assert np.array_equal(cnt, oc), (cnt, oc)
     assert cnt[0] == 0 and cnt[9] == 0xFFFFFFFF          # empty -> no result; overlong -> reference panics
     assert_same((ids, sc, cnt), (oi, os_, oc))
+
+
+def test_random_small_dictionaries_property():
+    """Randomised parity: tiny alphabets and short strings give many ties, repeated documents, repeated terms after
+    normalisation (pad), empty/short queries and cardinality windows that clip at the index edge."""
+    import random
+    from suggest_amd import NGramIndex, IndexDescription
+    rng = random.Random(1234)
+    for trial in range(12):
+        q = rng.choice([1, 2, 3, 3, 4])
+        alpha = rng.choice([("english",), ("english", "numbers"), ("ab", "$"), ("russian", "english", "numbers", "$")])
+        wrap = rng.choice([("$", "$"), ("^", "$"), ("", ""), (" ", " ")])
+        pad = rng.choice(["$", "_", ""]) if q <= 4 else "$"
+        syms = rng.choice(["ab", "abc -", "abcdefgh 12", "абвгд ёab", "AbC.dE f"])
+        docs = ["".join(rng.choice(syms) for _ in range(rng.randint(0, 14))) for _ in range(rng.randint(1, 400))]
+        if not ora_tokens_ok(docs[0], q, wrap, pad, alpha):
+            docs[0] = "abcabcab"            # the reference panics if the FIRST document has no tokens (indexer_writer.go:70)
+        desc = dict(ngram_size=q, wrap=wrap, pad=pad, alphabet=alpha)
+        gpu = NGramIndex(docs, IndexDescription(**desc))
+        ora = oracle.OracleIndex(docs, **desc)
+        queries = [rng.choice(docs) for _ in range(40)] + ["".join(rng.choice(syms) for _ in range(rng.randint(0, 18))) for _ in range(60)]
+        qb, qo = oracle.pack_strings(queries)
+        for metric, a in (("jaccard", rng.choice([0.2, 0.5, 0.9])), ("cosine", rng.choice([0.3, 0.6])), ("dice", 0.4),
+                          ("overlap", rng.choice([0.5, 1.0])), ("exact", 1.0)):
+            k = rng.choice([1, 3, 10, 70])
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k),
+                        ora.suggest_batch(qb, qo, metric, a, k), queries)
+        ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=7)
+        oi, oc, _ = ora.autocomplete_batch(qb, qo, 7)
+        assert np.array_equal(cnt, oc), (trial, desc)
+        valid = np.arange(7)[None, :] < cnt[:, None]
+        assert np.array_equal(ids[valid], oi[valid]), (trial, desc)
+
+
+def ora_tokens_ok(doc, q, wrap, pad, alpha):
+    return len(oracle.OracleIndex([doc], ngram_size=q, wrap=wrap, pad=pad, alphabet=alpha).tokenize(doc)) > 0
+
+
+def test_identity_round_trip_at_1m():
+    """Size-independent property at 1 M strings: a dictionary string queried verbatim comes back first with score
+    exactly 1.0 (or an identical string with a smaller docID), for every metric."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    blob, offs = synth.make_dict(1000000, seed=1)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
+    pick = np.arange(0, 1000000, 977)[:1024]
+    docs = synth.unpack(blob, offs)
+    qs = [docs[i] for i in pick]
+    qb, qo = oracle.pack_strings(qs)
+    for metric, a in (("jaccard", 0.5), ("cosine", 0.4), ("dice", 0.5)):
+        ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=10)
+        assert (cnt >= 1).all()
+        assert (sc[:, 0] == 1.0).all()
+        assert all(docs[int(ids[r, 0])] == qs[r] and int(ids[r, 0]) <= int(pick[r]) for r in range(len(qs)))
+        # scores are non-increasing and ties are ordered by ascending docID
+        for r in range(len(qs)):
+            c = int(cnt[r])
+            assert all(sc[r, j] > sc[r, j + 1] or (sc[r, j] == sc[r, j + 1] and ids[r, j] < ids[r, j + 1]) for j in range(c - 1))
