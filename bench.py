@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of results to every rank")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: include the optional RCCL all_gather of the k*(u32,f64) result rows in every timed step "
+                         "(default: results stay sharded — the path has no data-path collective; one untimed gather validates RCCL)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run (profiles/), reported as roofline.traffic")
     args = ap.parse_args()
@@ -85,7 +87,7 @@ def main():
     d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev)
     d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
-    if world > 1 and not args.no_gather:
+    if world > 1:
         g_ids = torch.zeros((world * n_q, k), dtype=torch.int32, device=dev)
         g_sc = torch.zeros((world * n_q, k), dtype=torch.float64, device=dev)
         g_cnt = torch.zeros(world * n_q, dtype=torch.int32, device=dev)
@@ -95,8 +97,8 @@ def main():
         index.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k,
                                    d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr(), stream=stream.cuda_stream)
 
-    def gather():
-        if world > 1 and not args.no_gather:   # top-k gather over RCCL/xGMI: k*(u32,f64) per query
+    def gather(force=False):
+        if world > 1 and (args.gather or force):   # top-k gather over RCCL/xGMI: k*(u32,f64) per query
             dist.all_gather_into_tensor(g_ids, d_ids)
             dist.all_gather_into_tensor(g_sc, d_sc)
             dist.all_gather_into_tensor(g_cnt, d_cnt)
@@ -125,6 +127,12 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    gather_ok = None
+    if world > 1:                       # untimed functional check of the optional result gather over RCCL
+        gather(force=True)
+        torch.cuda.synchronize(dev)
+        mine = slice(rank * n_q, (rank + 1) * n_q)
+        gather_ok = bool(torch.equal(g_ids[mine], d_ids) and torch.equal(g_cnt[mine], d_cnt))
 
     ids = d_ids.cpu().numpy().view(np.uint32)
     sc = d_sc.cpu().numpy()
@@ -181,7 +189,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU"
                                    % (_human(args.dict_size), args.ngram, args.metric, args.similarity, k, n_q),
-                       "parallelism": "query-sharded x%d, index replica per GPU%s" % (world, "" if world == 1 or args.no_gather else ", RCCL all_gather of results"),
+                       "parallelism": "query-sharded x%d, index replica per GPU%s" % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
+                       "rccl_gather_check": gather_ok,
                        "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"]},
                        "results_per_query": float(np.minimum(cnt, k).mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

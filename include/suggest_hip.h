@@ -63,6 +63,11 @@ enum sg_error {
  * cardinality-segmented inverted index as term-major CSR in host memory. */
 int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out);
 
+/* NewFSBuilder + Reader.Read (pkg/suggest/ngram_index_builder.go:44-83, pkg/index/index_reader.go:29-120): loads an
+ * index the reference itself built — <name>.hd (gob header) and <name>.dl (VB / skip-VB / roaring posting lists,
+ * pkg/index/codec.go:39-51) — into the same CSR.  `desc` must be the IndexDescription the files were built with. */
+int sg_index_load_reference(const char* hd_path, const char* dl_path, const sg_desc* desc, sg_index** out);
+
 /* Copies the CSR index into the HBM of `device` (one replica per GPU; per-process). */
 int sg_index_upload(sg_index* index, int device);
 

@@ -1249,6 +1249,23 @@ int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, c
   return SG_OK;
 }
 
+int sg_index_load_reference(const char* hd_path, const char* dl_path, const sg_desc* desc, sg_index** out) {
+  if (!out || !hd_path || !dl_path) { set_error("null argument"); return SG_E_INVALID; }
+  auto* ix = new (std::nothrow) sg_index();
+  if (!ix) return SG_E_NOMEM;
+  std::string err;
+  int rc;
+  try {
+    rc = load_reference_index(hd_path, dl_path, desc, ix->host, err);
+  } catch (const std::bad_alloc&) { rc = SG_E_NOMEM; err = "out of host memory"; }
+  if (rc) { set_error(err); delete ix; return rc; }
+  if (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX) {
+    set_error("wrap strings longer than 8 runes"); delete ix; return SG_E_UNSUPPORTED;
+  }
+  *out = ix;
+  return SG_OK;
+}
+
 int sg_index_upload(sg_index* ix, int device) {
   if (!ix) { set_error("null index"); return SG_E_INVALID; }
   if (ix->uploaded) return SG_OK;

@@ -226,8 +226,7 @@ bool tokenize_keys(const HostIndex& ix, const uint8_t* s, size_t n, bool autocom
   return true;
 }
 
-int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
-                     std::string& err) {
+int init_description(const sg_desc* desc, HostIndex& ix, std::string& err) {
   if (!desc || desc->ngram_size < 1 || desc->ngram_size > 8) { err = "ngram_size must be in 1..8"; return SG_E_INVALID; }
   ix.q = desc->ngram_size;
   ix.wrap0_s = desc->wrap_start ? desc->wrap_start : "";
@@ -236,7 +235,41 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
   for (uint32_t i = 0; i < desc->n_alphabet; i++) ix.alphabet_spec.emplace_back(desc->alphabet[i]);
   decode_all(ix.wrap0_s, ix.wrap0);
   decode_all(ix.wrap1_s, ix.wrap1);
-  int rc = build_symbols(ix, err);
+  return build_symbols(ix, err);
+}
+
+// key of an already normalised term string (every rune must be a symbol)
+bool term_string_key(const HostIndex& ix, const std::string& term, uint64_t* key) {
+  std::vector<uint32_t> rs;
+  decode_all(term, rs);
+  if (rs.size() > 8) return false;
+  uint64_t k = 0;
+  for (size_t i = 0; i < rs.size(); i++) {
+    uint8_t id; bool alpha;
+    sym_lookup(ix.sym, rs[i], &id, &alpha);
+    if (!id) return false;
+    k |= (uint64_t)id << (8 * i);
+  }
+  *key = k;
+  return true;
+}
+
+// term-key hash table (open addressing, linear probing, load <= 0.5)
+void build_term_table(HostIndex& ix) {
+  const size_t nT = ix.term_key.size();
+  size_t cap = 16;
+  while (cap < nT * 2) cap <<= 1;
+  ix.slots.assign(cap, TermSlot{0, kNoTerm, 0});
+  for (size_t t = 0; t < nT; t++) {
+    size_t h = mix64(ix.term_key[t]) & (cap - 1);
+    while (ix.slots[h].term != kNoTerm) h = (h + 1) & (cap - 1);
+    ix.slots[h] = TermSlot{ix.term_key[t], (uint32_t)t, 0};
+  }
+}
+
+int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
+                     std::string& err) {
+  int rc = init_description(desc, ix, err);
   if (rc) return rc;
   ix.n_docs = n_docs;
 
@@ -333,15 +366,7 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
     return x.doc < y.doc;
   });
 
-  // term-key hash table (open addressing, linear probing, load <= 0.5)
-  size_t cap = 16;
-  while (cap < nT * 2) cap <<= 1;
-  ix.slots.assign(cap, TermSlot{0, kNoTerm, 0});
-  for (size_t t = 0; t < nT; t++) {
-    size_t h = mix64(ix.term_key[t]) & (cap - 1);
-    while (ix.slots[h].term != kNoTerm) h = (h + 1) & (cap - 1);
-    ix.slots[h] = TermSlot{ix.term_key[t], (uint32_t)t, 0};
-  }
+  build_term_table(ix);
   return SG_OK;
 }
 

@@ -66,6 +66,12 @@ bool tokenize_keys(const HostIndex& ix, const uint8_t* s, size_t n, bool autocom
 int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
                      std::string& err);
 
+int init_description(const sg_desc* desc, HostIndex& ix, std::string& err);
+bool term_string_key(const HostIndex& ix, const std::string& term, uint64_t* key);
+void build_term_table(HostIndex& ix);
+// loads reference-built <name>.hd / <name>.dl (ref_index_reader.cpp)
+int load_reference_index(const char* hd_path, const char* dl_path, const sg_desc* desc, HostIndex& ix, std::string& err);
+
 // metric maths in IEEE double, evaluation order of pkg/metric/*.go (host copies; engine.hip has
 // the device twins)
 int metric_min_y(int m, double alpha, int size);

@@ -39,24 +39,43 @@ def _enc(s):
     return s.encode("utf-8") if isinstance(s, str) else bytes(s)
 
 
+def _c_desc(d):
+    alpha = (C.c_char_p * len(d.alphabet))(*[_enc(a) for a in d.alphabet])
+    desc = _lib.SgDesc(d.ngram_size, _enc(d.wrap[0]), _enc(d.wrap[1]), _enc(d.pad), alpha, len(d.alphabet))
+    desc._keep = alpha
+    return desc
+
+
 class NGramIndex:
-    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True):
+    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None):
         L = _lib.lib()
         d = description or IndexDescription()
         self.description = d
-        if blob is None:
-            blob, offs = pack_strings(docs)
-        blob = np.ascontiguousarray(blob, dtype=np.uint8)
-        offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        self.n_docs = len(offs) - 1
-        alpha = (C.c_char_p * len(d.alphabet))(*[_enc(a) for a in d.alphabet])
-        desc = _lib.SgDesc(d.ngram_size, _enc(d.wrap[0]), _enc(d.wrap[1]), _enc(d.pad), alpha, len(d.alphabet))
-        h = C.c_void_p()
-        _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
-        self._h = h
         self.device = None
+        if _handle is not None:
+            self._h = _handle
+            self.n_docs = self.stats()["n_docs"]
+        else:
+            if blob is None:
+                blob, offs = pack_strings(docs)
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
+            offs = np.ascontiguousarray(offs, dtype=np.uint64)
+            self.n_docs = len(offs) - 1
+            desc = _c_desc(d)
+            h = C.c_void_p()
+            _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
+            self._h = h
         if upload:
             self.upload(device)
+
+    @classmethod
+    def from_reference_files(cls, hd_path, dl_path, description, device=0, upload=True):
+        """NewFSBuilder (pkg/suggest/ngram_index_builder.go:44-52): open an index the reference built
+        (<name>.hd gob header + <name>.dl posting lists)."""
+        desc = _c_desc(description)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sg_index_load_reference(_enc(hd_path), _enc(dl_path), C.byref(desc), C.byref(h)))
+        return cls(description=description, device=device, upload=upload, _handle=h)
 
     def upload(self, device=0):
         _lib.check(_lib.lib().sg_index_upload(self._h, int(device)))

@@ -48,6 +48,27 @@ def read_dictionary(path):
     return [l[:-1] if l.endswith(b"\r") else l for l in lines]
 
 
+def read_cdb_dictionary(path):
+    """OpenCDBDictionary (pkg/dictionary/helpers.go:14-22, cdb_dictionary.go): D. J. Bernstein's constant database
+    written by BuildCDBDictionary (helpers.go:52-100) with key = docID as 4-byte little endian, value = the string.
+    Records start at byte 2048 and run to the first hash table; returned in docID order."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 2048:
+        raise IOError("failed to open cdb dictionary file: %s" % path)
+    end = min(struct.unpack_from("<I", data, 8 * i)[0] for i in range(256))
+    out = {}
+    pos = 2048
+    while pos < end:
+        klen, dlen = struct.unpack_from("<II", data, pos)
+        key = data[pos + 8:pos + 8 + klen]
+        out[struct.unpack("<I", key)[0] if klen == 4 else None] = data[pos + 8 + klen:pos + 8 + klen + dlen]
+        pos += 8 + klen + dlen
+    n = len(out)
+    return [out.get(i, b"") for i in range(n)]
+
+
 def read_configs(path):
     """ReadConfigs — pkg/suggest/config.go:84-112 (paths relative to the config file)"""
     with open(path, encoding="utf-8") as f:
@@ -75,9 +96,15 @@ class Service:
     def add_index_by_description(self, description):
         if description.driver == "RAM":
             return self.add_run_time_index(description)
-        # DISC driver: the reference opens a pre-built <name>.hd/.dl; the GPU engine rebuilds the CSR
-        # from the dictionary source instead (reading .hd/.dl directly is SURVEY §8f-2, a later row).
-        return self.add_run_time_index(description)
+        return self.add_on_disc_index(description)
+
+    def add_on_disc_index(self, description):
+        """AddOnDiscIndex (service.go:61-75): <output>/<name>.cdb dictionary + <name>.hd/.dl built by the reference's
+        indexer; the posting lists are decoded once and kept as CSR in HBM."""
+        base = os.path.join(description.output, description.name)
+        dictionary = read_cdb_dictionary(base + ".cdb")
+        index = NGramIndex.from_reference_files(base + ".hd", base + ".dl", description, device=self.device)
+        return self._install(description.name, index, dictionary)
 
     def add_run_time_index(self, description):
         if not description.source or not os.path.exists(description.source):
@@ -87,6 +114,9 @@ class Service:
     def add_index(self, name, dictionary, description):
         """dictionary: sequence of str/bytes, docID = position (dictionary.NewInMemoryDictionary)"""
         index = NGramIndex(dictionary, description, device=self.device)
+        return self._install(name, index, dictionary)
+
+    def _install(self, name, index, dictionary):
         with self._lock:                       # service.go:85-88
             old = self._indexes.get(name)
             self._indexes[name] = index
@@ -138,7 +168,7 @@ class Service:
     # Go-style aliases so reference call sites read the same
     AddIndexByDescription = add_index_by_description
     AddRunTimeIndex = add_run_time_index
-    AddOnDiscIndex = add_index_by_description
+    AddOnDiscIndex = add_on_disc_index
     AddIndex = add_index
     GetDictionaries = get_dictionaries
     Suggest = suggest

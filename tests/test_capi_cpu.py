@@ -73,7 +73,7 @@ def test_cars_csr_matches_reference_files(cars_lines, golden_dir):
     which the CSR keeps as a multiplicity side table): same keys, raw lengths, postings."""
     from suggest_amd import NGramIndex
     ix = NGramIndex(cars_lines, _desc(CARS_DESC), upload=False)
-    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "cars.hd"), os.path.join(golden_dir, "cars.dl"))
+    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "db", "cars.hd"), os.path.join(golden_dir, "db", "cars.dl"))
     mine = ix.lists()
     st = ix.stats()
     assert st["n_segments"] == n_idx and st["n_lists"] == len(ref) and st["n_postings_raw"] == sum(v[0] for v in ref.values())
@@ -100,3 +100,48 @@ def test_algorithmic_bytes_matches_oracle_definition():
     qs = synth.unpack(qb, qo)
     for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20)):
         assert ix.algorithmic_bytes(qb, qo, metric, alpha, k) == sum(ora.algorithmic_bytes(q, metric, alpha, k) for q in qs)
+
+
+def test_reference_built_files_load_into_the_same_csr(cars_lines, golden_dir):
+    """sg_index_load_reference: the gob header + VB / skip-VB lists of db/cars.{hd,dl} give exactly the CSR
+    that building from cars.dict gives (keys, raw lengths, postings), and match the independent Python decoder."""
+    from suggest_amd import NGramIndex
+    hd, dl = os.path.join(golden_dir, "db", "cars.hd"), os.path.join(golden_dir, "db", "cars.dl")
+    loaded = NGramIndex.from_reference_files(hd, dl, _desc(CARS_DESC), upload=False)
+    built = NGramIndex(cars_lines, _desc(CARS_DESC), upload=False)
+    a, b = loaded.lists(), built.lists()
+    assert a == b
+    sa, sb = loaded.stats(), built.stats()
+    for key in ("n_docs", "n_segments", "n_terms", "n_lists", "n_postings", "n_postings_raw", "posting_bytes"):
+        assert sa[key] == sb[key], key
+    n_idx, ref = refindex.read_index(hd, dl)
+    assert {k: (v[0], sorted(set(v[1]))) for k, v in ref.items()} == a
+
+
+def test_reference_built_roaring_lists_load(golden_dir):
+    """db/words_subset.{hd,dl} (subset of the reference's words index, bytes verbatim) holds all three codecs incl. 40
+    roaring bitmaps; the C++ loader must agree with the Python decoder list by list."""
+    from suggest_amd import NGramIndex
+    hd, dl = os.path.join(golden_dir, "db", "words_subset.hd"), os.path.join(golden_dir, "db", "words_subset.dl")
+    loaded = NGramIndex.from_reference_files(hd, dl, _desc(WORDS_DESC), upload=False).lists()
+    n_idx, ref = refindex.read_index(hd, dl)
+    assert sum(1 for v in ref.values() if v[0] > 256) == 40
+    assert {k: (v[0], sorted(set(v[1]))) for k, v in ref.items()} == loaded
+
+
+def test_loader_rejects_bad_inputs(golden_dir, tmp_path):
+    from suggest_amd import NGramIndex, IndexDescription, _lib
+    hd, dl = os.path.join(golden_dir, "db", "cars.hd"), os.path.join(golden_dir, "db", "cars.dl")
+    with pytest.raises(_lib.SuggestHipError):
+        NGramIndex.from_reference_files(hd + ".nope", dl, _desc(CARS_DESC), upload=False)
+    with pytest.raises(_lib.SuggestHipError):      # alphabet that cannot express the stored terms
+        NGramIndex.from_reference_files(hd, dl, IndexDescription(alphabet=("numbers",), pad="#"), upload=False)
+    bad = tmp_path / "bad.hd"
+    bad.write_bytes(open(hd, "rb").read()[:1000])
+    with pytest.raises(_lib.SuggestHipError):
+        NGramIndex.from_reference_files(str(bad), dl, _desc(CARS_DESC), upload=False)
+
+
+def test_cdb_dictionary_matches_the_source_lines(cars_lines, golden_dir):
+    from suggest_amd.service import read_cdb_dictionary
+    assert read_cdb_dictionary(os.path.join(golden_dir, "db", "cars.cdb")) == cars_lines

@@ -241,3 +241,19 @@ def test_identity_round_trip_at_1m():
         for r in range(len(qs)):
             c = int(cnt[r])
             assert all(sc[r, j] > sc[r, j + 1] or (sc[r, j] == sc[r, j + 1] and ids[r, j] < ids[r, j + 1]) for j in range(c - 1))
+
+
+def test_service_disc_driver_golden(reference_tests, golden_dir):
+    """TestConcurrencyOnDisc (pkg/suggest/service_test.go:11-80): testdata/config.json verbatim, DISC driver — the index
+    files and the CDB dictionary the reference committed are opened directly."""
+    import os
+    from suggest_amd import CosineMetric, SearchConfig, Service, read_configs
+    descriptions = read_configs(os.path.join(golden_dir, "config.json"))
+    assert descriptions[0].driver == "DISC"
+    svc = Service()
+    svc.AddIndexByDescription(descriptions[0])
+    t = reference_tests["service_cars"]
+    for q, exp in zip(t["queries"], t["expected_values"]):
+        res = svc.Suggest("cars", SearchConfig(q, t["topK"], CosineMetric(), t["similarity"]))
+        assert [r.value for r in res] == exp, q
+    assert svc.GetDictionaries() == ["cars"]

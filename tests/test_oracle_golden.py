@@ -124,7 +124,7 @@ def test_service_cars(reference_tests, cars_lines, cars_index):
 def test_cars_index_matches_reference_files(cars_index, golden_dir):
     """Every (segment, term) list of the oracle-built cars index equals the list the reference
     wrote to db/cars.{hd,dl}: same keys, same raw lengths, same postings incl. duplicates."""
-    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "cars.hd"), os.path.join(golden_dir, "cars.dl"))
+    n_idx, ref = refindex.read_index(os.path.join(golden_dir, "db", "cars.hd"), os.path.join(golden_dir, "db", "cars.dl"))
     mine = cars_index.lists()
     assert cars_index.n_segments == n_idx == 52
     assert set(mine) == set(ref) and len(ref) == 36285

@@ -3,7 +3,10 @@
 where /root/reference exists; the GPU box only ever sees the committed outputs).
 
 Only DATA is carried over (inputs and expected outputs the reference's tests hold):
-  cars.dict, cars.hd, cars.dl, config.json   copied verbatim from pkg/suggest/testdata[/db]
+  cars.dict, config.json, db/cars.{hd,dl,cdb} copied verbatim from pkg/suggest/testdata[/db]
+  db/words_subset.{hd,dl}                    a SUBSET of pkg/suggest/testdata/db/words.{hd,dl}: the lists of a few edge
+                                             segments plus the longest (roaring-coded) lists, posting-list bytes
+                                             verbatim, header re-encoded as gob with the original type messages
   words.dict.xz                              pkg/suggest/testdata/words.dict, xz-compressed
   words_index_digest.json                    digest of pkg/suggest/testdata/db/words.{hd,dl}
                                              decoded with tests/refindex.py (the 4 MB .dl is not committed)
@@ -32,14 +35,81 @@ def segment_digests(lists):
     return {str(s): [v[0], v[1], v[2].hexdigest()] for s, v in per.items()}
 
 
+def _gob_uint(v):
+    if v < 128:
+        return bytes([v])
+    b = v.to_bytes((v.bit_length() + 7) // 8, "big")
+    return bytes([256 - len(b)]) + b
+
+
+def _gob_int(v):
+    return _gob_uint((~v << 1) | 1 if v < 0 else v << 1)
+
+
+def write_words_subset():
+    """db/words_subset.{hd,dl}: edge segments + the 40 longest lists of words.{hd,dl} (all three codecs)."""
+    hd = open(os.path.join(REF, "db", "words.hd"), "rb").read()
+    dl = open(os.path.join(REF, "db", "words.dl"), "rb").read()
+    version, indices, terms = refindex.read_header(os.path.join(REF, "db", "words.hd"))
+    # type-definition messages (negative type ids) are copied verbatim; find where the value message starts
+    g = refindex._Gob(memoryview(hd))
+    type_id = None
+    while g.i < len(hd):
+        start = g.i
+        n = g.uint()
+        end = g.i + n
+        tid = g.int_()
+        if tid >= 0:
+            type_id, value_start = tid, start
+            break
+        g.i = end
+    longest = sorted(terms, key=lambda t: -t[4])[:40]
+    keep = [t for t in terms if t[1] in (1, 2, 3, 4, 21, 22, 23, 24)] + longest
+    keep = sorted(set(keep), key=lambda t: (t[1], t[0]))
+    out_dl = bytearray()
+    body = bytearray()
+    body += _gob_int(type_id)
+    body += _gob_uint(1) + _gob_uint(len(version)) + version.encode()        # field 0 Version
+    body += _gob_uint(1) + _gob_uint(indices)                                 # field 1 Indices
+    body += _gob_uint(1) + _gob_uint(len(keep))                               # field 2 Terms
+    for term, indice, size, pos, length in keep:
+        new_pos = len(out_dl)
+        out_dl += dl[pos:pos + size]
+        rec = bytearray()
+        f = -1
+        for idx, val in enumerate((term, indice, size, new_pos, length)):
+            if idx == 0:
+                if len(val) == 0:
+                    continue
+                rec += _gob_uint(idx - f) + _gob_uint(len(val)) + val
+            else:
+                if val == 0:
+                    continue
+                rec += _gob_uint(idx - f) + _gob_uint(val)
+            f = idx
+        body += rec + b"\x00"
+    body += b"\x00"
+    with open(os.path.join(OUT, "db", "words_subset.hd"), "wb") as f:
+        f.write(hd[:value_start] + _gob_uint(len(body)) + bytes(body))
+    with open(os.path.join(OUT, "db", "words_subset.dl"), "wb") as f:
+        f.write(bytes(out_dl))
+    # self-check with the reader
+    n_idx, lists = refindex.read_index(os.path.join(OUT, "db", "words_subset.hd"), os.path.join(OUT, "db", "words_subset.dl"))
+    assert n_idx == indices and len(lists) == len(keep)
+    classes = [sum(1 for v in lists.values() if lo <= v[0] <= hi) for lo, hi in ((0, 65), (66, 256), (257, 1 << 30))]
+    print("words subset:", len(keep), "lists, codec classes", classes, "dl bytes", len(out_dl))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name in ("cars.dict", "config.json"):
         shutil.copyfile(os.path.join(REF, name), os.path.join(OUT, name))
-    for name in ("cars.hd", "cars.dl"):
-        shutil.copyfile(os.path.join(REF, "db", name), os.path.join(OUT, name))
-    for name in ("cars.dict", "config.json", "cars.hd", "cars.dl"):
+    os.makedirs(os.path.join(OUT, "db"), exist_ok=True)
+    for name in ("cars.hd", "cars.dl", "cars.cdb"):
+        shutil.copyfile(os.path.join(REF, "db", name), os.path.join(OUT, "db", name))
+    for name in ("cars.dict", "config.json", "db/cars.hd", "db/cars.dl", "db/cars.cdb"):
         os.chmod(os.path.join(OUT, name), 0o644)
+    write_words_subset()
     with open(os.path.join(REF, "words.dict"), "rb") as f:
         raw = f.read()
     with open(os.path.join(OUT, "words.dict.xz"), "wb") as f:
