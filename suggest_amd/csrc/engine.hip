@@ -35,6 +35,7 @@ namespace sg {
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
 #define SG_T_FLOOR 8       // lowest flag threshold list skipping may leave
+#define SG_ROWTAB_CAP 160  // row descriptors (16 B) per streaming window
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -628,7 +629,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* rows = term + SG_MAX_A;
   uint32_t* cand = rows + SG_ROWS_CAP;
   uint32_t* candw = cand + SG_CAND_CAP;             // segment (within the tile) of each queued candidate
-  uint32_t* dummy_w = candw + SG_CAND_CAP + 32;     // 32 words of verdict staging behind the queue, then one
+  uint32_t* rowtab = candw + SG_CAND_CAP + 32;      // 32 words of verdict staging behind the queue, then the row table (16-byte aligned)
+  uint32_t* dummy_w = rowtab + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL);   // then one
   const uint32_t dummy_lane = (uint32_t)(uintptr_t)(lds_u32*)(dummy_w + lane);   // private dummy counter word per lane
   uint32_t* dup_scratch = dummy_w + 64;
   uint32_t* tk_id_lds = dup_scratch + SG_DUP_SCRATCH;
@@ -929,14 +931,15 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         DBG_COUNT(3, 1)
         __syncthreads();
       };
-      // slow path of one counted batch: rows u = 0..3 hold list jl[u] from chunk cb[u] on; visits only the
+      // slow path of one counted batch whose row descriptors are rows4[0..3]; visits only the
       // flagged postings (per-lane bit mask, then uniform dynamic indexing of the register vectors)
       auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
-                         const uint32_t (&jl)[SG_UNROLL], const uint32_t (&cb)[SG_UNROLL], uint32_t Tm1) {
+                         const uint4* rows4, uint32_t Tm1) {
         const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
                            v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
-        const uint32_t __attribute__((ext_vector_type(4))) jv = {jl[0], jl[1], jl[2], jl[3]};
-        const uint32_t __attribute__((ext_vector_type(4))) cv = {cb[0], cb[1], cb[2], cb[3]};
+        const uint4 t0 = rows4[0], t1 = rows4[1], t2 = rows4[2], t3 = rows4[3];   // the batch's row descriptors (LDS)
+        const uint32_t __attribute__((ext_vector_type(4))) jv = {t0.z, t1.z, t2.z, t3.z};
+        const uint32_t __attribute__((ext_vector_type(4))) cv = {t0.x, t1.x, t2.x, t3.x};
         uint32_t fl = 0;
 #pragma unroll
         for (int ue = 0; ue < 4 * SG_UNROLL; ue++) fl |= ((live[ue >> 2] && was[ue] >= Tm1) ? 1u : 0u) << ue;
@@ -992,11 +995,10 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
         const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
-        auto stream_rows = [&](auto two_tag) {
-        constexpr bool TWO = decltype(two_tag)::value;
-        // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the
-        // running row number where they start (pr, wave scan); row R belongs to the one lane with
-        // pr <= R < pr+nr, found by a ballot — no scalar branching, no LDS.
+        // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the running
+        // row number where they start (pr, wave scan) and writes their descriptors {first chunk, live lanes,
+        // list} to the LDS row table; the stream loop then needs one uniform LDS read per row — no ballots,
+        // no VALU->SALU->readlane dependency chains.  Tables larger than SG_ROWTAB_CAP are done in windows.
         uint32_t nr[2], pr[2];
         uint32_t n_rows = 0;
 #pragma unroll
@@ -1007,55 +1009,55 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           pr[r] = n_rows + incl - nr[r];
           n_rows += readlane(incl, 63);
         }
-        uint32_t next_row = 0;
-        uint4 v[SG_UNROLL], vn[SG_UNROLL];
-        uint32_t live[SG_UNROLL], liven[SG_UNROLL], jl[SG_UNROLL], jln[SG_UNROLL], cb[SG_UNROLL], cbn[SG_UNROLL];
-        u32x16 was;
-        auto fetch = [&](uint4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL], uint32_t (&jj)[SG_UNROLL], uint32_t (&cc)[SG_UNROLL]) {
+        uint4* rowtab4 = (uint4*)rowtab;
+        for (uint32_t w0 = 0; w0 < n_rows && !DBG_SKIP(512u); w0 += SG_ROWTAB_CAP) {
+          const uint32_t wn = min((uint32_t)SG_ROWTAB_CAP, n_rows - w0);
+          __syncthreads();
 #pragma unroll
-          for (int u = 0; u < SG_UNROLL; u++) {
-            const uint32_t R = next_row + (uint32_t)u;
-            uint32_t s_, n_, p_, j_;
-            const uint64_t m0 = ballot(R - pr[0] < nr[0]);
-            if (!TWO || m0) {                                   // (compile-time true for queries of <= 64 terms: straight-line code)
-              const int li = m0 ? __builtin_ctzll(m0) : 0;
-              s_ = readlane(ls_r[0], li); n_ = m0 ? readlane(ln_r[0], li) : 0u; p_ = readlane(pr[0], li); j_ = (uint32_t)li;
-            } else {
-              const uint64_t m1 = ballot(R - pr[1] < nr[1]);
-              const int li = m1 ? __builtin_ctzll(m1) : 0;
-              s_ = readlane(ls_r[1], li); n_ = m1 ? readlane(ln_r[1], li) : 0u; p_ = readlane(pr[1], li); j_ = 64u + (uint32_t)li;
+          for (int r = 0; r < 2; r++) {
+            if (r < a_rounds) {
+              for (uint32_t x = 0; x < nr[r]; x++) {
+                const uint32_t R = pr[r] + x;
+                if (R >= w0 && R < w0 + wn)
+                  rowtab4[R - w0] = make_uint4(ls_r[r] + x * 64u, min(64u, ln_r[r] - x * 64u), (uint32_t)(r * 64 + lane), 0u);
+              }
             }
-            const uint32_t c0 = n_ ? (R - p_) << 6 : 0u;       // dead row (past the last): n_ = 0, adds nothing
-            const uint32_t c = c0 + (uint32_t)lane;
-            lv[u] = c < n_ ? 1u : 0u;
-            jj[u] = j_;
-            cc[u] = s_ + c0;
-            vv[u] = post4[s_ + min(c, n_ ? n_ - 1 : 0u)];
           }
-          next_row += SG_UNROLL;
-        };
-        // ping-pong between two register sets: the next batch's loads are in flight while one is counted
-        auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], const uint32_t (&pj)[SG_UNROLL],
-                           const uint32_t (&pc)[SG_UNROLL]) {
-          uint64_t any = 0;
-          if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
-          else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
-          DBG_COUNT(1, 1)
-          if (any) { PH(5) flagged(pv, pl, was, pj, pc, Tm1); PH(6) }
-        };
-        // fetches are unconditional (rows past the last are dead rows) so that the compiler can count the
-        // loads in flight: process(v) waits for v's four loads only (vmcnt(4)), not for the prefetched batch
-        const uint32_t n_batches = (n_rows + SG_UNROLL - 1) / SG_UNROLL;
-        fetch(v, live, jl, cb);
-        for (uint32_t bi = 0; bi < n_batches; bi += 2) {
-          fetch(vn, liven, jln, cbn);
-          process(v, live, jl, cb);
-          if (bi + 1 >= n_batches) break;
-          fetch(v, live, jl, cb);
-          process(vn, liven, jln, cbn);
+          if (lane < 2 * SG_UNROLL) rowtab4[wn + lane] = make_uint4(0u, 0u, 0u, 0u);   // dead rows behind the last batch
+          __syncthreads();
+          uint4 v[SG_UNROLL], vn[SG_UNROLL];
+          uint32_t live[SG_UNROLL], liven[SG_UNROLL];
+          u32x16 was;
+          uint32_t next_row = 0;
+          auto fetch = [&](uint4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL]) {
+#pragma unroll
+            for (int u = 0; u < SG_UNROLL; u++) {
+              const uint4 t = rowtab4[next_row + (uint32_t)u];   // uniform address: one broadcast LDS read
+              lv[u] = (uint32_t)lane < t.y ? 1u : 0u;
+              vv[u] = post4[t.x + min((uint32_t)lane, t.y ? t.y - 1 : 0u)];
+            }
+            next_row += SG_UNROLL;
+          };
+          // ping-pong between two register sets: the next batch's loads are in flight while one is counted
+          auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], uint32_t row0) {
+            uint64_t any = 0;
+            if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
+            else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
+            DBG_COUNT(1, 1)
+            if (any) { PH(5) flagged(pv, pl, was, rowtab4 + row0, Tm1); PH(6) }
+          };
+          // fetches are unconditional (rows past the last are dead rows) so that the compiler can count the
+          // loads in flight: process(v) waits for v's four loads only (vmcnt(4)), not for the prefetched batch
+          const uint32_t n_batches = (wn + SG_UNROLL - 1) / SG_UNROLL;
+          fetch(v, live);
+          for (uint32_t bi = 0; bi < n_batches; bi += 2) {
+            fetch(vn, liven);
+            process(v, live, bi * SG_UNROLL);
+            if (bi + 1 >= n_batches) break;
+            fetch(v, live);
+            process(vn, liven, (bi + 1) * SG_UNROLL);
+          }
         }
-        };
-        if (a_rounds > 1) stream_rows(std::true_type{}); else stream_rows(std::false_type{});
         PH(5)
         if (!(u8 && saturated)) break;
         // re-run with u32 counters: candidates already verified stay in the dedup set (emitted once)
@@ -1178,7 +1180,8 @@ const LowerPair kLowerPairs[] = {
 };
 
 size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 64 + SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
+  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + 64 +
+                 SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
