@@ -561,9 +561,11 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
     for (int e = 0; e < 4; e++) {
       lds_u32* w = counter_word(dv[e], am, cb);
       if (U8) {
-        const uint32_t sh = (dv[e] & 3u) << 3;
+        // byte lane = docID & 3: the shift amount is (d << 3) mod 32 — the hardware shifters and v_bfe use
+        // only the low 5 bits, so no masking instruction is needed (dead lanes add into their dummy word)
+        const uint32_t sh = dv[e] << 3;
         shf[u * 4 + e] = sh;
-        old[u * 4 + e] = __hip_atomic_fetch_add(w, live[u] << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old[u * 4 + e] = __hip_atomic_fetch_add(w, 1u << (sh & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
         old[u * 4 + e] = __hip_atomic_fetch_add(w, live[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -576,7 +578,7 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       uint32_t o = old[u * 4 + e];
-      if (U8) o = (o >> shf[u * 4 + e]) & 0xFFu;
+      if (U8) o = __builtin_amdgcn_ubfe(o, shf[u * 4 + e], 8u);   // v_bfe_u32 reads offset[4:0] only
       was[u * 4 + e] = o;
       mu = max(mu, o);
     }
