@@ -799,13 +799,14 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       qn = 0;
     };
 
-    // buckets a group needs once its longest lists are skipped down to SG_T_FLOOR (estimate: equal lengths)
-    const float inv_A = 1.0f / (float)A;
-    auto need_after_skip = [&](uint32_t chunks, int T) -> uint32_t {
-      const int k = (T > SG_T_FLOOR && !DBG_SKIP(8u)) ? min(T - SG_T_FLOOR, A - 1) : 0;
-      const uint32_t rem = chunks - (uint32_t)((float)chunks * (float)k * inv_A);
-      return buckets_needed(rem * 4u, T - k);
-    };
+    // buckets a segment needs once its longest lists are skipped down to SG_T_FLOOR (estimate: equal
+    // lengths), computed by the segment's own lane; groups are then cut by accumulating these.
+    uint32_t seg_need = 0;
+    if (seg_valid) {
+      const int k = (seg_T > SG_T_FLOOR && !DBG_SKIP(8u)) ? min(seg_T - SG_T_FLOOR, A - 1) : 0;
+      const uint32_t rem = seg_tot - (uint32_t)((float)seg_tot * (float)k * (1.0f / (float)A));
+      seg_need = max(1u, buckets_needed(rem * 4u, seg_T - k));
+    }
 
     int wnext = DBG_SKIP(16u) ? Wt : 0;
     while (wnext < Wt) {
@@ -814,15 +815,15 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       const int g0 = __builtin_ctzll(rest);
       int g1 = g0;
       uint32_t L = readlane(seg_tot, g0);                     // 16-byte chunks of the group
+      uint32_t need_acc = readlane(seg_need, g0);
       int Tmin = (int)readlane((uint32_t)seg_T, g0);
       // merge following valid segments while the counters still resolve the group
       for (;;) {
         const int nx = g1 + 1;
         if (nx >= Wt || !((vmask >> nx) & 1)) break;
-        const uint32_t nt = readlane(seg_tot, nx);
-        const int tm = min(Tmin, (int)readlane((uint32_t)seg_T, nx));
-        if (need_after_skip(L + nt, tm) > max_buckets) break;
-        L += nt; Tmin = tm; g1 = nx;
+        const uint32_t nn = readlane(seg_need, nx);
+        if (need_acc + nn > max_buckets) break;
+        need_acc += nn; L += readlane(seg_tot, nx); Tmin = min(Tmin, (int)readlane((uint32_t)seg_T, nx)); g1 = nx;
       }
       wnext = g1 + 1;
 
@@ -838,34 +839,33 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       //      in >= T of the n lists is in >= T-k of ANY n-k of them, so k lists need not be streamed
       //      if postings are flagged at T-k; the exact overlap always comes from the verification over
       //      all lists.  Any k lists are valid; up to T - SG_T_FLOOR lists are taken in tiers of
-      //      relative length (> 3x, 2x, 1.5x, 1x, 0.75x, 0.5x the mean), longest tiers first. ----
+      //      relative length (> 2x, 1.25x, 1x, 0.5x the mean), longest tiers first, lowest lanes first
+      //      inside a tier (rank among the tier's lanes by v_mbcnt: no loops). ----
       uint64_t skip_m[2] = {0, 0};
       int Teff = Tmin;
       uint32_t Leff = L;
       if (Tmin > SG_T_FLOOR && !DBG_SKIP(8u)) {
-        const int k_allowed = Tmin - SG_T_FLOOR;
         const uint32_t n_ne = popc64(ballot(ln_r[0] != 0)) + (a_rounds > 1 ? popc64(ballot(ln_r[1] != 0)) : 0u);
-        const uint32_t x0 = ln_r[0] * n_ne, x1 = ln_r[1] * n_ne;
-        const uint32_t th[6] = {L * 3u, L * 2u, L + (L >> 1), L, L - (L >> 2), L >> 1};
+        const uint32_t th[4] = {L * 2u, L + (L >> 2), L, L >> 1};
         uint64_t pick0 = 0, pick1 = 0;
-        int budget = k_allowed;
+        int budget = Tmin - SG_T_FLOOR;
+        auto take = [&](uint32_t x, uint32_t thr, uint64_t& pick) {
+          const uint64_t m = ballot(x > thr) & ~pick;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          const uint64_t keep = ballot(((m >> lane) & 1ull) && (int)rank < budget);
+          pick |= keep;
+          budget -= (int)popc64(keep);
+        };
+        const uint32_t x0 = ln_r[0] * n_ne;
 #pragma unroll
-        for (int f = 0; f < 6; f++) {
-          if (budget > 0) {
-            uint64_t m0 = ballot(x0 > th[f]) & ~pick0;
-            while ((int)popc64(m0) > budget) m0 &= ~(1ull << (63 - __builtin_clzll(m0)));
-            pick0 |= m0; budget -= (int)popc64(m0);
-            if (a_rounds > 1 && budget > 0) {
-              uint64_t m1 = ballot(x1 > th[f]) & ~pick1;
-              while ((int)popc64(m1) > budget) m1 &= ~(1ull << (63 - __builtin_clzll(m1)));
-              pick1 |= m1; budget -= (int)popc64(m1);
-            }
-          }
+        for (int f = 0; f < 4; f++) {
+          if (budget > 0) take(x0, th[f], pick0);
+          if (a_rounds > 1 && budget > 0) take(ln_r[1] * n_ne, th[f], pick1);
         }
-        const int k_skip = (int)(popc64(pick0) + popc64(pick1));
-        if (k_skip > 0) {
+        if (pick0 | pick1) {
           const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
           const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
+          const int k_skip = (int)(popc64(pick0) + popc64(pick1));
           if (buckets_needed((L - skipped) * 4u, Tmin - k_skip) <= max_buckets) {
             skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
           }
