@@ -30,12 +30,12 @@ namespace sg {
 #define SG_CAND_CAP 64
 #define SG_K_LDS 64
 #define SG_WRAP_MAX 8
-#define SG_ROWS_CAP 768    // u32 entries of seg_off rows kept in LDS per tile
+#define SG_ROWS_CAP 512    // u32 entries of seg_off rows kept in LDS per tile
 #define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
 #define SG_T_FLOOR 8       // lowest flag threshold list skipping may leave
-#define SG_ROWTAB_CAP 160  // row descriptors (16 B) per streaming window
+#define SG_ROWTAB_CAP 96   // row descriptors (16 B) per streaming window
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -415,8 +415,9 @@ __device__ uint32_t d_lower_bound_u32(const uint32_t* p, uint32_t n, uint32_t ke
 // overlap #{merged lists holding >= j copies} + #{probed lists holding the doc} and is collected if that
 // reaches T; the intersector (n == T) collects the doc once per copy in the shortest list
 // (list_intersector.go:37-70).  fm0/fm1 = query terms (lanes, round 0/1) whose list in the doc's segment
-// holds it.  Writes the extra overlaps to scratch[2*SG_MAX_A+64 ..] and returns their number; `scratch` is its
-// own LDS region (the counters may be live: the overflow pass emits while it still reads them).
+// holds it.  Writes the extra overlaps to scratch[2*SG_MAX_A+64 ..] and returns their number; `scratch` is the
+// row-table region, idle whenever candidates are emitted (NOT the counters: the overflow pass emits while it
+// still reads them).
 // (A real call would cost the kernel ~100 VGPRs: kept inline.)
 __device__ __forceinline__ int dup_secondary_overlaps(const DeviceIndex& ix, const uint32_t* term, const uint32_t* rows,
                                                    uint32_t* scratch, int A, uint32_t stride, int w, uint32_t B, int T,
@@ -634,8 +635,9 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* rowtab = candw + SG_CAND_CAP + 32;      // 32 words of verdict staging behind the queue, then the row table (16-byte aligned)
   uint32_t* dummy_w = rowtab + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL);   // then one
   const uint32_t dummy_lane = (uint32_t)(uintptr_t)(lds_u32*)(dummy_w + lane);   // private dummy counter word per lane
-  uint32_t* dup_scratch = dummy_w + 64;
-  uint32_t* tk_id_lds = dup_scratch + SG_DUP_SCRATCH;
+  uint32_t* dup_scratch = rowtab;                   // the repeated-term path runs between streams: it borrows the row table
+  static_assert(SG_DUP_SCRATCH <= 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL), "dup scratch must fit the row table");
+  uint32_t* tk_id_lds = dummy_w + 64;
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
@@ -1148,7 +1150,7 @@ struct sg_index {
   DeviceIndex dix{};
   std::vector<void*> allocs;
   uint64_t device_bytes = 0;
-  uint32_t log2_cnt = 10;
+  uint32_t log2_cnt = 11;
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -1183,7 +1185,7 @@ const LowerPair kLowerPairs[] = {
 
 size_t lds_bytes(uint32_t log2_cnt) {
   size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + 64 +
-                 SG_DUP_SCRATCH + SG_K_LDS + SG_K_LDS * 2;
+                 SG_K_LDS + SG_K_LDS * 2;
   return words * 4;
 }
 
