@@ -34,7 +34,6 @@ namespace sg {
 #define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
-#define SG_T_FLOOR 8       // lowest flag threshold list skipping may leave
 #define SG_ROWTAB_CAP 96   // row descriptors (16 B) per streaming window
 
 struct DeviceIndex {
@@ -77,6 +76,8 @@ struct BatchArgs {
   uint32_t n_q, k;
   int metric, autocomplete;
   uint32_t log2_cnt;    // LDS counter words per wave = 1 << log2_cnt
+  int t_floor;          // lowest flag threshold list skipping may leave
+  uint32_t filter_level;  // row of kBucketsPer16Postings: how rarely a bucket may reach T by chance
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -521,9 +522,15 @@ __device__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
 
 // Buckets a group of `postings` postings needs so that a bucket reaching T by chance is rare
 // (a false candidate only costs a slot in the batched verification): postings / lambda(T).
-__device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T) {
-  // 16/lambda(T) with lambda = 4, 3.2, 2, 1.23, 0.5, 0.31, 0.125 postings per bucket
-  const uint32_t m16 = T >= 14 ? 4u : T >= 12 ? 5u : T >= 10 ? 8u : T >= 8 ? 13u : T >= 6 ? 32u : T == 5 ? 51u : 128u;
+// m16[level][T] = ceil(16 / lambda): lambda = postings per bucket at which a bucket reaches T by chance with
+// probability 3e-5 / 1e-5 / 3e-6 / 1e-6 (Poisson tail; generated with scipy.stats.poisson).  T > 32 uses T = 32.
+__device__ const uint8_t kBucketsPer16Postings[4][33] = {
+    {255, 255, 255, 255, 95, 47, 28, 19, 14, 11, 9, 7, 6, 6, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2},
+    {255, 255, 255, 255, 126, 59, 35, 23, 17, 13, 10, 8, 7, 6, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2},
+    {255, 255, 255, 255, 171, 76, 43, 28, 19, 15, 12, 9, 8, 7, 6, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2},
+    {255, 255, 255, 255, 226, 95, 52, 33, 23, 17, 13, 11, 9, 7, 6, 6, 5, 5, 4, 4, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2}};
+__device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T, uint32_t level) {
+  const uint32_t m16 = kBucketsPer16Postings[level][T < 0 ? 0 : (T > 32 ? 32 : T)];
   return (postings * m16) >> 4;
 }
 
@@ -801,13 +808,13 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       qn = 0;
     };
 
-    // buckets a segment needs once its longest lists are skipped down to SG_T_FLOOR (estimate: equal
+    // buckets a segment needs once its longest lists are skipped down to a.t_floor (estimate: equal
     // lengths), computed by the segment's own lane; groups are then cut by accumulating these.
     uint32_t seg_need = 0;
     if (seg_valid) {
-      const int k = (seg_T > SG_T_FLOOR && !DBG_SKIP(8u)) ? min(seg_T - SG_T_FLOOR, A - 1) : 0;
+      const int k = (seg_T > a.t_floor && !DBG_SKIP(8u)) ? min(seg_T - a.t_floor, A - 1) : 0;
       const uint32_t rem = seg_tot - (uint32_t)((float)seg_tot * (float)k * (1.0f / (float)A));
-      seg_need = max(1u, buckets_needed(rem * 4u, seg_T - k));
+      seg_need = max(1u, buckets_needed(rem * 4u, seg_T - k, a.filter_level));
     }
 
     int wnext = DBG_SKIP(16u) ? Wt : 0;
@@ -840,17 +847,17 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       // ---- skip the longest lists (the pigeonhole behind CPMerge, cp_merge.go:22-31): a doc that is
       //      in >= T of the n lists is in >= T-k of ANY n-k of them, so k lists need not be streamed
       //      if postings are flagged at T-k; the exact overlap always comes from the verification over
-      //      all lists.  Any k lists are valid; up to T - SG_T_FLOOR lists are taken in tiers of
+      //      all lists.  Any k lists are valid; up to T - a.t_floor lists are taken in tiers of
       //      relative length (> 2x, 1.25x, 1x, 0.5x the mean), longest tiers first, lowest lanes first
       //      inside a tier (rank among the tier's lanes by v_mbcnt: no loops). ----
       uint64_t skip_m[2] = {0, 0};
       int Teff = Tmin;
       uint32_t Leff = L;
-      if (Tmin > SG_T_FLOOR && !DBG_SKIP(8u)) {
+      if (Tmin > a.t_floor && !DBG_SKIP(8u)) {
         const uint32_t n_ne = popc64(ballot(ln_r[0] != 0)) + (a_rounds > 1 ? popc64(ballot(ln_r[1] != 0)) : 0u);
         const uint32_t th[4] = {L * 2u, L + (L >> 2), L, L >> 1};
         uint64_t pick0 = 0, pick1 = 0;
-        int budget = Tmin - SG_T_FLOOR;
+        int budget = Tmin - a.t_floor;
         auto take = [&](uint32_t x, uint32_t thr, uint64_t& pick) {
           const uint64_t m = ballot(x > thr) & ~pick;
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
           const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
           const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
           const int k_skip = (int)(popc64(pick0) + popc64(pick1));
-          if (buckets_needed((L - skipped) * 4u, Tmin - k_skip) <= max_buckets) {
+          if (buckets_needed((L - skipped) * 4u, Tmin - k_skip, a.filter_level) <= max_buckets) {
             skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
           }
         }
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = buckets_needed(Leff * 4u, Teff);
+      const uint32_t need = buckets_needed(Leff * 4u, Teff, a.filter_level);
       bool u8 = need > cnt_words && Teff <= 200;
       uint32_t lg = 8;
       {
@@ -1151,6 +1158,8 @@ struct sg_index {
   std::vector<void*> allocs;
   uint64_t device_bytes = 0;
   uint32_t log2_cnt = 11;
+  int t_floor = 10;
+  uint32_t filter_level = 2;
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -1217,6 +1226,8 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
   a.metric = metric;
   a.autocomplete = autocomplete;
   a.log2_cnt = index->log2_cnt;
+  a.t_floor = index->t_floor;
+  a.filter_level = index->filter_level;
   a.prof = (unsigned long long*)g_prof_buf;
 #ifdef SG_PHASE_TIMING
   { const char* e = getenv("SG_DEBUG_SKIP"); a.dbg_skip = e ? (uint32_t)atoi(e) : 0u; }
@@ -1327,6 +1338,10 @@ int sg_index_upload(sg_index* ix, int device) {
   ix->device = device;
   const char* env = getenv("SG_LOG2_CNT");   // tuning knob: LDS counter words per wavefront (default 1024)
   if (env) { int v = atoi(env); if (v >= 9 && v <= 14) ix->log2_cnt = (uint32_t)v; }
+  env = getenv("SG_T_FLOOR");                 // tuning knob: lowest flag threshold list skipping may leave (default 10)
+  if (env) { int v = atoi(env); if (v >= 2 && v <= 64) ix->t_floor = v; }
+  env = getenv("SG_FILTER_LEVEL");            // tuning knob: 0..3 = chance of a false bucket 3e-5 .. 1e-6 (default 2)
+  if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->filter_level = (uint32_t)v; }
   HIP_TRY(hipFuncSetAttribute((const void*)sg_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes(14)));
   ix->uploaded = true;

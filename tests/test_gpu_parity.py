@@ -257,3 +257,48 @@ def test_service_disc_driver_golden(reference_tests, golden_dir):
         res = svc.Suggest("cars", SearchConfig(q, t["topK"], CosineMetric(), t["similarity"]))
         assert [r.value for r in res] == exp, q
     assert svc.GetDictionaries() == ["cars"]
+
+
+def test_saturating_bucket_and_candidate_overflow():
+    """300 identical documents whose docIDs share their low 12 bits: every posting of a query term lands in the same
+    counter bucket (a u8 counter would saturate -> the group is re-run with u32 counters) and the group has far more
+    than 64 distinct candidates (-> second pass over the final counters).  Most documents are empty strings."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    docs = [b""] * (300 * 4096)
+    for i in range(300):
+        docs[i * 4096] = b"saturating bucket"
+    docs[0] = b"saturating bucket"
+    docs[5] = b"saturating buckets"
+    docs[77] = b"saturation bucket"
+    desc = dict(synth.DESCRIPTION)
+    gpu = NGramIndex(docs, IndexDescription(**desc))
+    ora = oracle.OracleIndex(docs, **desc)
+    queries = [b"saturating bucket", b"saturatin bucket", b"saturating buckets", b"zzz"]
+    qb, qo = oracle.pack_strings(queries)
+    for metric, a, k in (("jaccard", 0.5, 10), ("cosine", 0.6, 400), ("dice", 0.9, 1000)):
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k),
+                    ora.suggest_batch(qb, qo, metric, a, k), queries)
+    ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=50)
+    oi, oc, _ = ora.autocomplete_batch(qb, qo, 50)
+    assert np.array_equal(cnt, oc)
+    valid = np.arange(50)[None, :] < cnt[:, None]
+    assert np.array_equal(ids[valid], oi[valid])
+
+
+@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9"),
+                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12"),
+                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10")])
+def test_results_do_not_depend_on_tuning_knobs(monkeypatch, knobs):
+    """The lossy counters are only a filter (every flagged doc is verified exactly), so list-skipping depth,
+    bucket-table strictness and counter-array size must not change a single output bit (DESIGN.md §4 knobs)."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    for name, v in knobs.items():
+        monkeypatch.setenv(name, v)
+    desc = dict(synth.DESCRIPTION)
+    blob, offs = synth.make_dict(300000, seed=21)
+    qb, qo = synth.make_queries(1024, blob, offs, seed=22)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+    for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.35, 50), ("overlap", 0.6, 5)):
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
+                    ora.suggest_batch(qb, qo, metric, alpha, k))
