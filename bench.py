@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--metric", default="jaccard")
     ap.add_argument("--similarity", type=float, default=0.5)
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--dict-variant", default="uniform", choices=["uniform", "skewed", "families", "skewed-families"],
+                    help="SURVEY.md §8d dictionary variants (headline = uniform); families = base + 3 edited copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
     ap.add_argument("--gather", action="store_true",
@@ -71,7 +73,8 @@ def main():
     # ---- workload -------------------------------------------------------------------------
     desc_kw = dict(synth.DESCRIPTION, ngram_size=args.ngram)
     t0 = time.time()
-    blob, offs = synth.make_dict(args.dict_size, seed=1)
+    blob, offs = synth.make_dict(args.dict_size, seed=1, skewed="skewed" in args.dict_variant,
+                                 families=3 if "families" in args.dict_variant else 0)
     qb, qo = synth.make_queries(args.queries, blob, offs, seed=2, start=rank * args.queries)
     log("dict %d strings + %d queries generated in %.1fs" % (args.dict_size, args.queries, time.time() - t0))
     t0 = time.time()
@@ -187,8 +190,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 (posting/counter work) + f64 (final score)",
             "data": "synthetic",
-            "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU"
-                                   % (_human(args.dict_size), args.ngram, args.metric, args.similarity, k, n_q),
+            "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]%s), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU"
+                                   % (_human(args.dict_size), "" if args.dict_variant == "uniform" else ", variant " + args.dict_variant,
+                                      args.ngram, args.metric, args.similarity, k, n_q),
                        "parallelism": "query-sharded x%d, index replica per GPU%s" % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
                        "rccl_gather_check": gather_ok,
                        "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"]},

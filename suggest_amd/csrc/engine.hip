@@ -38,6 +38,7 @@ namespace sg {
 
 struct DeviceIndex {
   const uint32_t* postings;
+  const uint32_t* cut_sample;  // [ceil(n_chunks/16)+1] docID of the first posting of every 16th chunk of the posting store
   const uint32_t* seg_off;
   const TermSlot* slots;
   const uint8_t* ascii_sym;    // [128]
@@ -745,7 +746,6 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     };
     auto flush_queue = [&]() {
       __syncthreads();
-      DBG_COUNT(4, qn ? 1 : 0)
       for (uint32_t c0 = 0; c0 < qn; c0 += 4) {                  // 4 candidates x A lists searched interleaved
         uint32_t qd[4], qw[4];
         bool ok[4];
@@ -976,25 +976,77 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       uint32_t n_pass = 1;
       if (g0 == g1) { while (n_pass < 1024u && need > max_buckets * n_pass) n_pass <<= 1; }
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
-      uint32_t prev_e[2] = {0, 0};                              // per list: first posting of the current docID range
+      uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
+      uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
       uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;
       for (uint32_t pass = 0; pass < n_pass; pass++) {
+      DBG_COUNT(4, 1)
       if (n_pass > 1) {
         lo_doc = (uint32_t)(((uint64_t)ix.n_docs * pass) / n_pass);
         hi_doc = pass + 1 == n_pass ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)ix.n_docs * (pass + 1)) / n_pass);
+        // Cut every list at hi_doc.  The cut need not be exact: any [lo, hi] around the true lower bound will do
+        // (the pass ends at hi, the next one starts at lo; a few postings counted twice only loosen the filter).
+        // Binary-searching the lists themselves costs ~17 random 128 B lines per list and pass — as much HBM
+        // traffic as the postings the pass streams (PMC: TCC_EA0_RDREQ 1.65x the algorithmic volume).  Instead a
+        // cursor per list advances over cut_sample (contiguous, one u32 per 64 postings, 1.6 % of the store) to
+        // the 16-chunk block that straddles hi_doc: no probe of the list, <= 64 postings of slack per cut.
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-          uint32_t e = full_ln[r] * 4;                          // first posting with doc >= hi_doc
-          if (pass + 1 != n_pass && full_ln[r]) {
-            const uint32_t* p = ix.postings + (uint64_t)full_ls[r] * 4;
-            uint32_t lo = prev_e[r], hi = full_ln[r] * 4;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[mid] < hi_doc) lo = mid + 1; else hi = mid; }
-            e = lo;
+          const uint32_t n = full_ln[r] * 4;
+          uint32_t lo = prev_lo[r], hi = n;
+          if (pass + 1 != n_pass && r < a_rounds) {
+            const uint32_t s0 = full_ls[r], g_first = (s0 + 15u) >> 4, g_end = (s0 + full_ln[r] + 15u) >> 4;
+            // bracket [glo, ghi]: every sample before glo is < hi_doc, sample ghi is >= hi_doc (or ghi == g_end).
+            // 8 independent loads per round: around the position the remaining samples predict when the cursor
+            // has far to go (docIDs of a list are close to uniform), then 9-ary, then 8 consecutive samples.
+            uint32_t glo = g_cur[r], ghi = g_end;
+            const uint32_t step = (g_end - glo) / (n_pass - pass);
+            bool predict = true;
+            while (ballot(glo < ghi)) {
+              uint32_t pos[8], sv[8];
+              const uint32_t span = ghi - glo;
+              const uint32_t m = 2u + (step >> 1), base = glo + step > m ? glo + step - m : 0u;
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                uint32_t x = span <= 8u || (predict && step <= 6u) ? glo + (uint32_t)i
+                             : predict ? base + (2u * m * (uint32_t)i) / 7u : glo + (span * (uint32_t)(i + 1)) / 9u;
+                pos[i] = min(max(x, glo), g_end);
+                sv[i] = ix.cut_sample[pos[i]];
+              }
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                if (pos[i] < g_end && sv[i] < hi_doc) glo = max(glo, pos[i] + 1u); else ghi = min(ghi, pos[i]);
+              }
+              glo = min(glo, ghi);
+              predict = false;
+            }
+            const uint32_t g = ghi;
+            g_cur[r] = g;
+            lo = max(lo, g > g_first ? ((((g - 1u) << 4) - s0) << 2) : 0u);
+            hi = min(n, g < g_end ? (((g << 4) - s0) << 2) : n);
+            lo = min(lo, hi);
+            // one round of probes inside the straddling block (two 128 B lines this pass and the next stream anyway):
+            // short lists get cuts to within two chunks — with many passes a 64-posting slack would re-read them whole
+            const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
+            while (ballot(hi - lo > 8u)) {
+              uint32_t pos[8], val[8];
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                pos[i] = min(lo + ((hi - lo) * (uint32_t)(i + 1)) / 9u, n ? n - 1u : 0u);
+                val[i] = n ? p[pos[i]] : 0xFFFFFFFFu;
+              }
+              uint32_t nlo = lo, nhi = hi;
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                if (val[i] < hi_doc) nlo = max(nlo, pos[i] + 1u); else nhi = min(nhi, pos[i]);
+              }
+              lo = min(nlo, nhi); hi = nhi;
+            }
           }
-          const uint32_t c_start = prev_e[r] >> 2, c_end = (e + 3) >> 2;   // rounded outwards to whole chunks
+          const uint32_t c_start = prev_lo[r] >> 2, c_end = (hi + 3) >> 2;   // rounded outwards to whole chunks
           ls_r[r] = full_ls[r] + c_start;
-          ln_r[r] = c_end - c_start;
-          prev_e[r] = e;
+          ln_r[r] = c_end > c_start ? c_end - c_start : 0u;
+          prev_lo[r] = lo;
         }
         lg = u8 ? a.log2_cnt + 2 : a.log2_cnt;                 // all buckets for every pass
         overflow = false;
@@ -1232,6 +1284,10 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
 #ifdef SG_PHASE_TIMING
   { const char* e = getenv("SG_DEBUG_SKIP"); a.dbg_skip = e ? (uint32_t)atoi(e) : 0u; }
 #endif
+  int prev_dev = -1;   // the launch goes to the index's device whatever the calling thread's current device is
+  HIP_TRY(hipGetDevice(&prev_dev));
+  if (prev_dev != index->device) HIP_TRY(hipSetDevice(index->device));
+  struct Restore { int d, want; ~Restore() { if (d != want) (void)hipSetDevice(d); } } restore{prev_dev, index->device};
   void* scratch = nullptr;
   if (k > SG_K_LDS) {  // top-k working rows in HBM (stream-ordered allocation)
     HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
@@ -1292,6 +1348,12 @@ int sg_index_upload(sg_index* ix, int device) {
   DeviceIndex& d = ix->dix;
   int rc;
   if ((rc = to_device(ix, h.postings.data(), h.postings.size(), &d.postings))) return rc;
+  {  // one sample per 64 postings of the store: lets a docID-range pass cut its lists without probing them
+    const size_t n_chunks = h.postings.size() / 4;
+    std::vector<uint32_t> cs(n_chunks / 16 + 2, 0xFFFFFFFFu);
+    for (size_t g = 0; g * 16 < n_chunks; g++) cs[g] = h.postings[g * 64];
+    if ((rc = to_device(ix, cs.data(), cs.size(), &d.cut_sample))) return rc;
+  }
   if ((rc = to_device(ix, h.seg_off.data(), h.seg_off.size(), &d.seg_off))) return rc;
   if ((rc = to_device(ix, h.slots.data(), h.slots.size(), &d.slots))) return rc;
   if ((rc = to_device(ix, h.sym.ascii_sym, 128, &d.ascii_sym))) return rc;

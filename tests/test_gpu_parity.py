@@ -302,3 +302,48 @@ def test_results_do_not_depend_on_tuning_knobs(monkeypatch, knobs):
     for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.35, 50), ("overlap", 0.6, 5)):
         assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
                     ora.suggest_batch(qb, qo, metric, alpha, k))
+
+
+@pytest.mark.parametrize("variant", [dict(skewed=True), dict(families=3), dict(skewed=True, families=3)])
+def test_skewed_and_family_dictionaries(variant):
+    """SURVEY.md §8d dictionary variants: Zipf-distributed symbols (long lists) and families of near-duplicates
+    (several matches per query: top-k eviction and score ties decided by docID)."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    desc = dict(synth.DESCRIPTION)
+    blob, offs = synth.make_dict(200000, seed=31, **variant)
+    qb, qo = synth.make_queries(1024, blob, offs, seed=32)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+    for metric, alpha, k in (("jaccard", 0.5, 10), ("jaccard", 0.3, 2), ("cosine", 0.4, 20), ("dice", 0.6, 3)):
+        got = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k)
+        assert_same(got, ora.suggest_batch(qb, qo, metric, alpha, k))
+    if variant.get("families"):
+        assert (got[2] >= 3).mean() > 0.3          # the variant does what it is for: many queries fill k=3
+
+
+def test_concurrent_callers_share_one_handle(synth_small):
+    """Suggest is called concurrently from arbitrary goroutines on one index; the C ABI must be
+    re-entrant on a shared handle (per-call stream and buffers).  ctypes releases the GIL during the call."""
+    import threading
+    gpu, ora, qb, qo = synth_small
+    n = len(qo) - 1
+    want = ora.suggest_batch(qb, qo, "jaccard", 0.5, 10)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(4):
+                lo, hi = (t * 37 + rep * 11) % (n // 2), n
+                sb, so = qb[int(qo[lo]):int(qo[hi])], qo[lo:hi + 1] - qo[lo]
+                ids, sc, cnt = gpu.suggest_batch(blob=sb, offs=so, metric="jaccard", similarity=0.5, k=10)
+                assert np.array_equal(cnt, want[2][lo:hi])
+                valid = np.arange(10)[None, :] < cnt[:, None]
+                assert np.array_equal(ids[valid], want[0][lo:hi][valid])
+                assert np.array_equal(sc.view(np.uint64)[valid], want[1][lo:hi].view(np.uint64)[valid])
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors

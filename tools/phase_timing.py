@@ -17,10 +17,12 @@ ap.add_argument("--queries", type=int, default=65536)
 ap.add_argument("--metric", default="jaccard")
 ap.add_argument("--similarity", type=float, default=0.5)
 ap.add_argument("--topk", type=int, default=10)
+ap.add_argument("--ngram", type=int, default=3)
+ap.add_argument("--dict-variant", default="uniform")
 args = ap.parse_args()
-blob, offs = synth.make_dict(args.dict_size, seed=1)
+blob, offs = synth.make_dict(args.dict_size, seed=1, skewed="skewed" in args.dict_variant, families=3 if "families" in args.dict_variant else 0)
 qb, qo = synth.make_queries(args.queries, blob, offs, seed=2)
-ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
+ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**dict(synth.DESCRIPTION, ngram_size=args.ngram)))
 dev = torch.device("cuda", 0)
 prof = torch.zeros(2 * 4096 * 8, dtype=torch.int64, device=dev)
 L = _lib.lib()
@@ -46,7 +48,7 @@ print("SG_DEBUG_SKIP=%s kernel ms (instrumented build): %.3f" % (os.environ.get(
 allp = prof.cpu().numpy().astype(np.float64).reshape(2, 4096, 8).sum(axis=1) / 6
 p = allp[0]
 cn = allp[1] / n_q
-print('per query: groups %.1f batches %.1f flag_events %.1f queued %.2f flushes %.2f emitted %.2f skipped_chunks %.0f of %.0f' % tuple(cn))
+print('per query: groups %.1f batches %.1f flag_events %.1f queued %.2f passes %.1f emitted %.2f skipped_chunks %.0f of %.0f' % tuple(cn))
 names = ["tokenize", "tile rows + segment stats", "group setup (merge, scan, geometry)", "clear counters", "chunk directory",
          "stream (loads + count)", "slow path (flagged)", "top-k sort + output"]
 tot = p.sum()
