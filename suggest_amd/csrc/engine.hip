@@ -34,7 +34,8 @@ namespace sg {
 #define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
-#define SG_ROWTAB_CAP 96   // row descriptors (16 B) per streaming window
+#define SG_ROWTAB_CAP 96      // row descriptors (16 B) per streaming window
+#define SG_MAX_PARTS 32       // parts a heavy query is cut into
 
 struct DeviceIndex {
   const uint32_t* postings;
@@ -79,6 +80,16 @@ struct BatchArgs {
   uint32_t log2_cnt;    // LDS counter words per wave = 1 << log2_cnt
   int t_floor;          // lowest flag threshold list skipping may leave
   uint32_t filter_level;  // row of kBucketsPer16Postings: how rarely a bucket may reach T by chance
+  // ---- heavy queries are cut into parts (ranges of segments) that other wavefronts take over ----
+  uint32_t* split_ctl;    // [2] items taken (second launch), items queued (first launch); null: splitting off.  Zeroed per batch.
+  uint32_t* items;        // [item_cap][4] {query, seg_lo | seg_hi << 16, slot | part << 24, -}
+  uint32_t* slot_ctl;     // [slot_cap][2] parts finished, parts in total (slot = query number, queries >= slot_cap are not split)
+  uint64_t* part_s;       // [slot_cap][SG_MAX_PARTS][k] top-k of each part (unordered), score bits
+  uint32_t* part_id;      //   ... docIDs
+  uint32_t* part_n;       // [slot_cap][SG_MAX_PARTS] entries
+  uint32_t item_cap, slot_cap;
+  uint32_t split_chunks;  // 16-byte chunks of postings per part of a split query ...
+  uint32_t split_min;     // ... which is a query (tile) whose admissible lists hold at least this many
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -491,7 +502,7 @@ struct TopK {  // wave-uniform state; arrays live in LDS (k <= SG_K_LDS) or in t
   uint32_t worst_id, worst_pos;
 };
 
-__device__ void topk_recompute_worst(TopK& tk, int lane) {
+__device__ __forceinline__ void topk_recompute_worst(TopK& tk, int lane) {
   uint64_t ws = ~0ull; uint32_t wi = 0, wp = 0xFFFFFFFFu;
   for (uint32_t i = lane; i < tk.n; i += 64) {
     uint64_t s = tk.s[i]; uint32_t d = tk.id[i];
@@ -508,7 +519,7 @@ __device__ void topk_recompute_worst(TopK& tk, int lane) {
 }
 
 // topKQueue.Add (topk.go:82-102): keep the k best under (score desc, docID asc)
-__device__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
+__device__ __forceinline__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, int lane) {
   if (tk.n < tk.k) {
     if (lane == 0) { tk.s[tk.n] = s; tk.id[tk.n] = d; }
     tk.n++;
@@ -628,10 +639,12 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 // are verified exactly (binary searches in the term lists of the doc's own segment), scored and
 // offered to the wave's top-k.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
+// kParts = false: one workgroup per query (the batch launch).  kParts = true: the second launch, a few thousand
+// persistent wavefronts that take the queued parts of split queries off the item queue until it is empty.
+template <bool kParts>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
-  const uint32_t qi = blockIdx.x;
   const DeviceIndex& ix = a.ix;
   const uint32_t cnt_words = 1u << a.log2_cnt;
   uint32_t* cnt = smem;
@@ -651,19 +664,41 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   uint32_t* runes = cnt;
   uint64_t* keys = (uint64_t*)(cnt + SG_MAX_RUNES);
 
-  const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
   const uint32_t k = a.k;
+  PH_DECL
+  DBG_DECL
+
+  const bool splitting = a.split_ctl != nullptr;
+  const bool primary = !kParts;
+  uint32_t qi = blockIdx.x;
+  int r_lo = 0, r_hi = 0x7FFFFFFF;                      // segments this wavefront handles (a part of a split query)
+  uint32_t my_slot = 0xFFFFFFFFu, my_part = 0;
+  for (;;) {
+  if (kParts) {
+    const uint32_t n_items = min(__builtin_amdgcn_readfirstlane(a.split_ctl[1]), a.item_cap);   // queued by the first launch
+    if (n_items == 0u) break;
+    uint32_t idx = 0;
+    if (lane == 0) idx = __hip_atomic_fetch_add(a.split_ctl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (idx >= n_items) break;
+    const uint32_t* it = a.items + (uint64_t)idx * 4;
+    qi = __builtin_amdgcn_readfirstlane(it[0]);
+    if (qi == 0xFFFFFFFFu) continue;                    // a hole: reserved by a query that then found no room
+    r_lo = (int)(__builtin_amdgcn_readfirstlane(it[1]) & 0xFFFFu); r_hi = (int)(__builtin_amdgcn_readfirstlane(it[1]) >> 16);
+    my_slot = __builtin_amdgcn_readfirstlane(it[2]) & 0xFFFFFFu; my_part = __builtin_amdgcn_readfirstlane(it[2]) >> 24;
+    __syncthreads();
+  }
+  do {   // one query (or one part of one): `break` leaves it
+  const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
   uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
-  PH_DECL
-  DBG_DECL
-  if (DBG_SKIP(32u)) { if (lane == 0) a.out_counts[qi] = 0; return; }
+  if (DBG_SKIP(32u)) { if (lane == 0) a.out_counts[qi] = 0; break; }
   const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
   PH(0)
-  if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; return; }
-  if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; return; }
-  if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
+  if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; break; }
+  if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; break; }
+  if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; break; }
 
   const int S = (int)ix.S;
   int b_min, b_max;
@@ -673,9 +708,11 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     b_max = d_max_y(a.metric, a.alpha, A, S);             // suggester.go:54-59
     if (b_max >= S) b_max = S - 1;
     const int span = b_max - b_min + 1;                    // suggester.go:62 make(chan int, span)
-    if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; return; }
-    if (span == 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_DEADLOCK; return; }
+    if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; break; }
+    if (span == 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_DEADLOCK; break; }
   }
+  b_min = max(max(b_min, 0), r_lo);                        // a part of a split query: its range of segments
+  b_max = min(b_max, r_hi);
 
   TopK tk;
   const bool tk_in_lds = k <= SG_K_LDS;
@@ -688,7 +725,8 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   const int wt_max = min(SG_TILE_MAX, SG_ROWS_CAP / A - 1);   // A <= 128 -> >= 7
   const uint32_t max_buckets = cnt_words * 4u;                 // u8 mode
 
-  for (int tb = max(b_min, 0); tb <= b_max; tb += wt_max) {
+  uint32_t pushed = 0;                                         // parts of this query queued for the second launch
+  for (int tb = b_min; tb <= b_max; tb += wt_max) {
     const int Wt = min(wt_max, b_max - tb + 1);
     const uint32_t stride = (uint32_t)Wt + 1;
     // ---- chunk offsets of every query term for segments tb .. tb+Wt (searcher.go:38-58) ----
@@ -718,6 +756,51 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
       seg_valid = seg_valid && (int)ne >= seg_T;                     // searcher.go:32 (fewer present terms than T)
     }
     const uint64_t vmask = ballot(seg_valid);
+    // ---- split decision (first launch, top-k in LDS): a tile whose admissible lists hold >= 2 x split_chunks chunks
+    //      is cut into parts of consecutive segments of about equal volume, which are queued for the second launch;
+    //      this wavefront goes on with the next tile.  A lone heavy query would otherwise be one wavefront's serial
+    //      work (skewed dictionaries: 40x the mean) and set the batch's latency. ----
+    if (splitting && primary && k <= SG_K_LDS && qi < a.slot_cap) {
+      const uint32_t vol = seg_valid ? seg_tot : 0u;
+      const uint32_t incl = wave_scan_incl(vol, lane);
+      const uint32_t total = readlane(incl, 63);
+      const uint32_t P = min(min((uint32_t)SG_MAX_PARTS - 1u - pushed, total / max(a.split_chunks, 1u)), popc64(vmask));
+      if (P >= 2u && total >= a.split_min) {
+        // part of a segment: where the middle of its volume falls; parts are runs of consecutive valid segments
+        const uint32_t part_of = min(P - 1u, (uint32_t)(((uint64_t)(incl - vol + (vol >> 1)) * P) / max(total, 1u)));
+        uint32_t n_parts = 0;
+        for (uint32_t j = 0; j < P; j++) n_parts += ballot(seg_valid && part_of == j) ? 1u : 0u;
+        // room in the item queue: ONE fetch-add per splitting query (a CAS loop collapses when thousands of
+        // wavefronts reach this point together).  A reservation that runs over the end marks its slots as holes;
+        // once the queue is full nobody tries any more.
+        uint32_t base = 0xFFFFFFFFu;
+        if (lane == 0 && __hip_atomic_load(a.split_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.item_cap) {
+          base = __hip_atomic_fetch_add(a.split_ctl + 1, n_parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (base >= a.item_cap) base = 0xFFFFFFFFu;
+          else if (n_parts > a.item_cap - base) {
+            for (uint32_t x = base; x < a.item_cap; x++) a.items[(uint64_t)x * 4] = 0xFFFFFFFFu;
+            base = 0xFFFFFFFFu;
+          }
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base != 0xFFFFFFFFu) {
+          uint32_t dense = 0;
+          for (uint32_t j = 0; j < P; j++) {
+            const uint64_t mj = ballot(seg_valid && part_of == j);
+            if (!mj) continue;
+            if (lane == 0) {
+              uint32_t* it = a.items + (uint64_t)(base + dense) * 4;
+              it[0] = qi;
+              it[1] = (uint32_t)(tb + __builtin_ctzll(mj)) | ((uint32_t)(tb + 63 - __builtin_clzll(mj)) << 16);
+              it[2] = qi | ((pushed + dense) << 24);       // the parts' top-k rows are indexed by the query
+            }
+            dense++;
+          }
+          pushed += n_parts;
+          continue;                                          // this tile's parts run in the second launch
+        }
+      }
+    }
     PH(1)
 
     // ---- candidate queue of the tile: docs whose bucket reached the flag threshold wait here and are
@@ -1171,6 +1254,45 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
     flush_queue();
   }
 
+  // ---- a part of a split query hands its top-k over; the part that finishes last merges them all (top-k of a
+  //      union = top-k of the union of the parts' top-k: the order (score desc, docID asc) is total) ----
+  if (kParts || pushed) {
+    // (first launch: this wavefront's own tiles are one more part, and nobody has counted yet)
+    if (!kParts) { my_slot = qi; my_part = pushed; }
+    __syncthreads();
+    const uint64_t pbase = (uint64_t)my_slot * SG_MAX_PARTS;
+    for (uint32_t i = lane; i < tk.n; i += 64) {
+      a.part_s[(pbase + my_part) * k + i] = tk.s[i];
+      a.part_id[(pbase + my_part) * k + i] = tk.id[i];
+    }
+    if (lane == 0) a.part_n[pbase + my_part] = tk.n;
+    if (!kParts) {                                         // the queued parts all run later: count this one as finished
+      if (lane == 0) { a.slot_ctl[2 * qi] = 1u; a.slot_ctl[2 * qi + 1] = pushed + 1u; }
+      break;
+    }
+    // release: this part's rows are visible device-wide (across the XCDs' L2s) before it is counted; acquire: the
+    // part that counts last sees every other part's rows.  One fence pair per >= 1 MiB part.
+    uint32_t fin = 0;
+    if (lane == 0) fin = __hip_atomic_fetch_add(a.slot_ctl + 2 * my_slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    fin = __builtin_amdgcn_readfirstlane(fin);
+    const uint32_t n_parts = __builtin_amdgcn_readfirstlane(a.slot_ctl[2 * my_slot + 1]);   // written by the first launch
+    if (fin != n_parts) break;                             // somebody else finishes later and merges
+    for (uint32_t pp = 0; pp < n_parts; pp++) {
+      if (pp == my_part) continue;
+      const uint32_t np = __builtin_amdgcn_readfirstlane(a.part_n[pbase + pp]);
+      for (uint32_t i0 = 0; i0 < np; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint64_t es = i < np ? a.part_s[(pbase + pp) * k + i] : 0ull;
+        const uint32_t ed = i < np ? a.part_id[(pbase + pp) * k + i] : 0u;
+        const uint32_t cntl = min(64u, np - i0);
+        for (uint32_t l = 0; l < cntl; l++) {
+          const uint64_t sl = (uint64_t)readlane((uint32_t)es, (int)l) | ((uint64_t)readlane((uint32_t)(es >> 32), (int)l) << 32);
+          topk_insert(tk, sl, readlane(ed, (int)l), lane);
+        }
+      }
+    }
+  }
+
   // ---- GetCandidates (topk.go:127-147): best first (rank sort, out of place) ----
   __syncthreads();
   const uint32_t n = tk.n;
@@ -1188,8 +1310,14 @@ __global__ __launch_bounds__(64) void sg_search_kernel(const BatchArgs a) {
   }
   if (lane == 0) a.out_counts[qi] = n;
   PH(7)
-  PH_FLUSH
+  } while (0);
+  if (!kParts) break;
+  }
+  { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
+
+#define sg_search_kernel sg_search_kernel_t<false>
+#define sg_parts_kernel sg_search_kernel_t<true>
 
 // ------------------------------------------------------------------------------------------
 // host side: handle, upload, launches, C ABI
@@ -1212,6 +1340,11 @@ struct sg_index {
   uint32_t log2_cnt = 11;
   int t_floor = 10;
   uint32_t filter_level = 2;
+  uint32_t split_chunks = 65536;   // 1 MiB of postings per part at least; 0 = never split a query
+  double terms_per_doc = 0;
+  double max_term_chunks = 0;      // chunks of the longest term (all segments)
+  uint32_t parts_grid = 3072;      // wavefronts of the second launch (three per SIMD are resident)
+  double est_query_chunks = 0;     // expected 16-byte chunks of postings a query's terms hold (size-biased mean list x terms per doc)
 };
 
 #define HIP_TRY(expr)                                                                   \
@@ -1293,9 +1426,42 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
     HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
     a.scratch_s = (uint64_t*)scratch;
     a.scratch_id = (uint32_t*)((char*)scratch + (size_t)n_q * k * 8);
+  } else if (index->split_chunks) {
+    // Splitting pays (1) when the batch cannot fill the machine by itself: every query above 2 MiB of postings is cut
+    // into 1 MiB parts; (2) for the outliers of a big batch, which would otherwise be its tail: one wavefront streams
+    // ~1/3000 of the machine's rate, so a query holding more than 2x the expected volume and more than ~1/30000 of the
+    // batch's is cut into parts of a quarter of that.  A big batch of equally heavy queries is left alone.
+    const double batch_chunks = (double)n_q * index->est_query_chunks;
+    double smin = 2.0 * index->split_chunks;
+    if (n_q > 4096u) smin = std::max(smin, std::max(2.0 * index->est_query_chunks, batch_chunks / 30000.0));
+    a.split_min = (uint32_t)std::min(smin, 4.0e9);
+    a.split_chunks = std::max<uint32_t>(index->split_chunks, a.split_min / 4u);
+    // an index whose queries do not come near the threshold (4x the expected volume) pays nothing for the machinery
+    if (4.0 * index->est_query_chunks < (double)a.split_min) a.split_min = 0;
+  }
+  if (a.split_min) {
+    const size_t per_slot = (size_t)SG_MAX_PARTS * k * 12;
+    a.slot_cap = (uint32_t)std::min<size_t>(n_q, ((size_t)1 << 30) / per_slot);
+    a.item_cap = std::min<uint32_t>(std::max<uint32_t>(n_q * 4u, 4096u), 262144u);
+    const size_t o_items = 64, o_slot = o_items + (size_t)a.item_cap * 16, o_pn = o_slot + (size_t)a.slot_cap * 8,
+                 o_ps = (o_pn + (size_t)a.slot_cap * SG_MAX_PARTS * 4 + 15) & ~(size_t)15,
+                 o_pid = o_ps + (size_t)a.slot_cap * SG_MAX_PARTS * k * 8, total = o_pid + (size_t)a.slot_cap * SG_MAX_PARTS * k * 4;
+    HIP_TRY(hipMallocAsync(&scratch, total, stream));
+    HIP_TRY(hipMemsetAsync(scratch, 0, o_items, stream));    // queue control words
+    char* base = (char*)scratch;
+    a.split_ctl = (uint32_t*)base;
+    a.items = (uint32_t*)(base + o_items);
+    a.slot_ctl = (uint32_t*)(base + o_slot);
+    a.part_n = (uint32_t*)(base + o_pn);
+    a.part_s = (uint64_t*)(base + o_ps);
+    a.part_id = (uint32_t*)(base + o_pid);
   }
   hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
   HIP_TRY(hipGetLastError());
+  if (a.split_ctl) {     // the queued parts of split queries: persistent wavefronts, which leave at once if there are none
+    hipLaunchKernelGGL(sg_parts_kernel, dim3(index->parts_grid), dim3(64), lds_bytes(a.log2_cnt), stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   if (scratch) HIP_TRY(hipFreeAsync(scratch, stream));
   return SG_OK;
 }
@@ -1402,8 +1568,29 @@ int sg_index_upload(sg_index* ix, int device) {
   if (env) { int v = atoi(env); if (v >= 9 && v <= 14) ix->log2_cnt = (uint32_t)v; }
   env = getenv("SG_T_FLOOR");                 // tuning knob: lowest flag threshold list skipping may leave (default 10)
   if (env) { int v = atoi(env); if (v >= 2 && v <= 64) ix->t_floor = v; }
+  {  // a query term is a dictionary term drawn by occurrence: E[list length] = sum len^2 / sum len (size-biased)
+    const size_t S = h.n_segments, nt = h.term_key.size();
+    double s1 = 0, s2 = 0;
+    for (size_t t = 0; t < nt; t++) {
+      const double len = (double)(h.seg_off[t * (S + 1) + S] - h.seg_off[t * (S + 1)]);
+      s1 += len; s2 += len * len;
+      ix->max_term_chunks = std::max(ix->max_term_chunks, len);
+    }
+    const double terms_per_doc = h.n_docs ? (double)h.n_postings_raw / (double)h.n_docs : 0.0;
+    ix->est_query_chunks = s1 > 0 ? terms_per_doc * s2 / s1 : 0.0;
+    ix->terms_per_doc = terms_per_doc;
+    if (getenv("SG_VERBOSE")) fprintf(stderr, "[suggest_hip] terms/doc %.2f, expected query volume %.0f chunks, longest term %.0f chunks\n", terms_per_doc, ix->est_query_chunks, ix->max_term_chunks);
+  }
+  env = getenv("SG_SPLIT_CHUNKS");            // tuning knob: fewest 16-byte chunks per part of a split query (default 65536; 0 = off)
+  if (env && *env) ix->split_chunks = (uint32_t)std::max(0, atoi(env));
   env = getenv("SG_FILTER_LEVEL");            // tuning knob: 0..3 = chance of a false bucket 3e-5 .. 1e-6 (default 2)
   if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->filter_level = (uint32_t)v; }
+  HIP_TRY(hipFuncSetAttribute((const void*)sg_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(ix->log2_cnt)));
+  {  // per-launch scratch comes from the device's stream-ordered pool: keep freed blocks instead of returning them
+    hipMemPool_t pool;
+    uint64_t keep = ~0ull;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
   HIP_TRY(hipFuncSetAttribute((const void*)sg_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes(14)));
   ix->uploaded = true;

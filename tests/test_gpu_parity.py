@@ -285,9 +285,9 @@ def test_saturating_bucket_and_candidate_overflow():
     assert np.array_equal(ids[valid], oi[valid])
 
 
-@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9"),
-                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12"),
-                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10")])
+@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9", SG_SPLIT_CHUNKS="0"),
+                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12", SG_SPLIT_CHUNKS="8"),
+                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10", SG_SPLIT_CHUNKS="200")])
 def test_results_do_not_depend_on_tuning_knobs(monkeypatch, knobs):
     """The lossy counters are only a filter (every flagged doc is verified exactly), so list-skipping depth,
     bucket-table strictness and counter-array size must not change a single output bit (DESIGN.md §4 knobs)."""
@@ -347,3 +347,32 @@ def test_concurrent_callers_share_one_handle(synth_small):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+def test_split_queries_match_unsplit(monkeypatch, cars_lines, words_lines):
+    """Heavy queries are cut into parts (ranges of segments) run by other wavefronts and merged by the part that
+    finishes last (DESIGN.md §4 "split queries").  With SG_SPLIT_CHUNKS=1 every query with two valid segments is
+    split: the cars workload (documents returned twice), autocomplete and the words goldens must
+    not change by a bit."""
+    from suggest_amd import NGramIndex
+    monkeypatch.setenv("SG_SPLIT_CHUNKS", "1")
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]] + [b"", b"zzzzzz", b"NISSAN"]
+    qb, qo = oracle.pack_strings(queries)
+    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.2, 64), ("dice", 0.6, 3), ("cosine", 0.3, 200)]:
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
+                    ora.suggest_batch(qb, qo, metric, alpha, k), queries)
+    aq = [l[:n] for l in cars_lines[::9] for n in (3, 6)] + [b"AN "]
+    ab, ao = oracle.pack_strings(aq)
+    ids, cnt = gpu.autocomplete_batch(blob=ab, offs=ao, limit=20)
+    oi, oc, _ = ora.autocomplete_batch(ab, ao, 20)
+    assert np.array_equal(cnt, oc)
+    valid = np.arange(20)[None, :] < cnt[:, None]
+    assert np.array_equal(ids[valid], oi[valid])
+    gpu = NGramIndex(words_lines, _desc(WORDS_DESC))
+    ora = oracle.OracleIndex(words_lines, **WORDS_DESC)
+    queries = [w for w in words_lines[::499]] + [w[:-1] + b"q" for w in words_lines[5::999]]
+    qb, qo = oracle.pack_strings(queries)
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.4, k=10),
+                ora.suggest_batch(qb, qo, "jaccard", 0.4, 10), queries)
