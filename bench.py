@@ -45,7 +45,8 @@ def main():
                     help="N>1: include the optional RCCL all_gather of the k*(u32,f64) result rows in every timed step "
                          "(default: results stay sharded — the path has no data-path collective; one untimed gather validates RCCL)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a rocprofv3 --pmc run (profiles/), reported as roofline.traffic")
+                    help="HBM bytes per launch from a rocprofv3 --pmc run, reported as roofline.traffic (default: the figure "
+                         "recorded in profiles/traffic.json for this exact workload, measured with tools/pmc_run.sh)")
     args = ap.parse_args()
 
     import numpy as np
@@ -172,6 +173,15 @@ def main():
         parity = {"checked_queries": int(n_s), "bit_exact": bool(same)}
         log("cpu baseline %.0f q/s on %d threads; GPU result bit-exact vs oracle on the sample: %s" % (cpu["value"], used, same))
 
+    traffic, traffic_src = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes else None)
+    if traffic is None:      # PMC counters cannot be read inside this process: use the committed measurement of this workload
+        try:
+            key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (args.dict_size, n_q, args.ngram, args.metric, args.similarity, k, args.dict_variant)
+            rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+            if rec:
+                traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
+        except (OSError, ValueError):
+            pass
     if rank == 0:
         total_q = world * n_q * args.steps
         avg_ms = float(np.mean(kernel_ms))
@@ -198,7 +208,7 @@ def main():
                        "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"]},
                        "results_per_query": float(np.minimum(cnt, k).mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes, "kernel": "sg_search_kernel", "kernel_ms_avg": avg_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "sg_search_kernel", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_query": alg_bytes / n_q},
             "cpu_baseline": cpu,
         }
