@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--dict-variant", default="uniform", choices=["uniform", "skewed", "families", "skewed-families"],
                     help="SURVEY.md §8d dictionary variants (headline = uniform); families = base + 3 edited copies")
+    ap.add_argument("--build", default="device", choices=["device", "host"],
+                    help="index build: on the GPU (sg_index_build_device) or on the host (sg_index_build); same arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
     ap.add_argument("--gather", action="store_true",
@@ -79,9 +81,9 @@ def main():
     qb, qo = synth.make_queries(args.queries, blob, offs, seed=2, start=rank * args.queries)
     log("dict %d strings + %d queries generated in %.1fs" % (args.dict_size, args.queries, time.time() - t0))
     t0 = time.time()
-    index = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc_kw), device=local_rank)
+    index = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc_kw), device=local_rank, build=args.build)
     st = index.stats()
-    log("index built+uploaded in %.1fs: %s" % (time.time() - t0, st))
+    log("index built (%s) + uploaded in %.1fs: %s" % (args.build, time.time() - t0, st))
     alg_bytes = index.algorithmic_bytes(qb, qo, args.metric, args.similarity, args.topk)
 
     k = args.topk

@@ -63,6 +63,13 @@ enum sg_error {
  * cardinality-segmented inverted index as term-major CSR in host memory. */
 int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out);
 
+/* Same index, built on the GPU `device`: documents are tokenised by the kernel-side tokenizer, terms
+ * interned in a device hash table, postings radix-sorted and laid out as the same CSR — array for array identical to
+ * sg_index_build's (sg_index_digest).  Fails with SG_E_UNSUPPORTED when a document has more than SG_MAX_QUERY_TERMS
+ * n-grams (use sg_index_build).  The index still has to be uploaded with sg_index_upload. */
+int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device,
+                          sg_index** out);
+
 /* NewFSBuilder + Reader.Read (pkg/suggest/ngram_index_builder.go:44-83, pkg/index/index_reader.go:29-120): loads an
  * index the reference itself built — <name>.hd (gob header) and <name>.dl (VB / skip-VB / roaring posting lists,
  * pkg/index/codec.go:39-51) — into the same CSR.  `desc` must be the IndexDescription the files were built with. */
@@ -122,6 +129,9 @@ int64_t sg_index_list(const sg_index* index, uint32_t segment, uint64_t key, uin
                       uint64_t* raw_len);
 /* Enumerates the non-empty (segment, term) lists: fills up to cap entries, returns the total. */
 uint64_t sg_index_lists(const sg_index* index, uint32_t* out_segments, uint64_t* out_keys, uint64_t cap);
+
+/* 64-bit digests of the host CSR: postings, seg_off, list lengths, term keys (+ repeated-term table). */
+int sg_index_digest(const sg_index* index, uint64_t out[4]);
 
 /* Algorithmic bytes of a suggest batch: per query 4*sum of |postings| over every
  * admissible segment and present term + len(query) + 12*k.  Host-side accounting for bench.py. */

@@ -304,7 +304,7 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
     if (n_tok > SG_MAX_A) return -1;
   }
   __syncthreads();
-  for (uint32_t i = lane; i < n_tok; i += 64) term[i] = d_term_lookup(ix, keys[i]);
+  if (ix.slots) for (uint32_t i = lane; i < n_tok; i += 64) term[i] = d_term_lookup(ix, keys[i]);
   __syncthreads();
   return (int)n_tok;
 }
@@ -1377,6 +1377,31 @@ const LowerPair kLowerPairs[] = {
 #include "unicode_lower.inc"
 };
 
+// symbol tables, lower-case table, wrap and pad of the description: what the device tokeniser reads
+int upload_description(sg_index* ix, DeviceIndex& d) {
+  const HostIndex& h = ix->host;
+  int rc;
+  if ((rc = to_device(ix, h.sym.ascii_sym, 128, &d.ascii_sym))) return rc;
+  if ((rc = to_device(ix, h.sym.ascii_alpha, 128, &d.ascii_alpha))) return rc;
+  if ((rc = to_device(ix, h.sym.na_rune.data(), h.sym.na_rune.size(), &d.na_rune))) return rc;
+  if ((rc = to_device(ix, h.sym.na_sym.data(), h.sym.na_sym.size(), &d.na_sym))) return rc;
+  if ((rc = to_device(ix, h.sym.na_alpha.data(), h.sym.na_alpha.size(), &d.na_alpha))) return rc;
+  std::vector<uint32_t> lf, lt;
+  for (const auto& p : kLowerPairs) { lf.push_back(p.from); lt.push_back(p.to); }
+  if ((rc = to_device(ix, lf.data(), lf.size(), &d.lower_from))) return rc;
+  if ((rc = to_device(ix, lt.data(), lt.size(), &d.lower_to))) return rc;
+  d.n_na = (uint32_t)h.sym.na_rune.size();
+  d.n_lower = (uint32_t)lf.size();
+  d.q = h.q;
+  d.n_wrap0 = (uint32_t)h.wrap0.size();
+  d.n_wrap1 = (uint32_t)h.wrap1.size();
+  for (size_t i = 0; i < h.wrap0.size(); i++) d.wrap0[i] = h.wrap0[i];
+  for (size_t i = 0; i < h.wrap1.size(); i++) d.wrap1[i] = h.wrap1[i];
+  d.n_pad = h.sym.n_pad;
+  memcpy(d.pad_sym, h.sym.pad_sym, 8);
+  return SG_OK;
+}
+
 size_t lds_bytes(uint32_t log2_cnt) {
   size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + 64 +
                  SG_K_LDS + SG_K_LDS * 2;
@@ -1468,6 +1493,8 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
 
 }  // namespace
 
+#include "index_build.inc"
+
 extern "C" {
 
 const char* sg_last_error(void) { return g_err.c_str(); }
@@ -1486,6 +1513,46 @@ int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, c
     set_error("wrap strings longer than 8 runes"); delete ix; return SG_E_UNSUPPORTED;
   }
   *out = ix;
+  return SG_OK;
+}
+
+int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device, sg_index** out) {
+  if (!out || (!utf8 && n_docs) || !offs) { set_error("null argument"); return SG_E_INVALID; }
+  auto* ix = new (std::nothrow) sg_index();
+  if (!ix) return SG_E_NOMEM;
+  std::string err;
+  int rc;
+  try {
+    rc = init_description(desc, ix->host, err);
+    if (rc) set_error(err);
+    else rc = build_on_device(ix, utf8, offs, n_docs, device);
+  } catch (const std::bad_alloc&) {
+    set_error("out of host memory"); rc = SG_E_NOMEM;
+  }
+  for (void* p : ix->allocs) (void)hipFree(p);   // the description tables of the build; sg_index_upload makes its own
+  ix->allocs.clear();
+  ix->device_bytes = 0;
+  if (rc) { delete ix; return rc; }
+  *out = ix;
+  return SG_OK;
+}
+
+int sg_index_digest(const sg_index* ix, uint64_t out[4]) {
+  if (!ix || !out) { set_error("null argument"); return SG_E_INVALID; }
+  const HostIndex& h = ix->host;
+  auto fold = [](const void* p, size_t bytes) {
+    uint64_t acc = 0x9E3779B97F4A7C15ull ^ bytes;
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); acc = mix64(acc ^ w); }
+    for (; i < bytes; i++) acc = mix64(acc ^ b[i]);
+    return acc;
+  };
+  out[0] = fold(h.postings.data(), h.postings.size() * 4);
+  out[1] = fold(h.seg_off.data(), h.seg_off.size() * 4);
+  out[2] = fold(h.list_len.data(), h.list_len.size() * 4);
+  out[3] = fold(h.term_key.data(), h.term_key.size() * 8) ^ mix64(h.dups.size() * 4 + h.n_segments) ^
+           fold(h.dups.data(), h.dups.size() * sizeof(DupEntry));
   return SG_OK;
 }
 
@@ -1522,15 +1589,7 @@ int sg_index_upload(sg_index* ix, int device) {
   }
   if ((rc = to_device(ix, h.seg_off.data(), h.seg_off.size(), &d.seg_off))) return rc;
   if ((rc = to_device(ix, h.slots.data(), h.slots.size(), &d.slots))) return rc;
-  if ((rc = to_device(ix, h.sym.ascii_sym, 128, &d.ascii_sym))) return rc;
-  if ((rc = to_device(ix, h.sym.ascii_alpha, 128, &d.ascii_alpha))) return rc;
-  if ((rc = to_device(ix, h.sym.na_rune.data(), h.sym.na_rune.size(), &d.na_rune))) return rc;
-  if ((rc = to_device(ix, h.sym.na_sym.data(), h.sym.na_sym.size(), &d.na_sym))) return rc;
-  if ((rc = to_device(ix, h.sym.na_alpha.data(), h.sym.na_alpha.size(), &d.na_alpha))) return rc;
-  std::vector<uint32_t> lf, lt;
-  for (const auto& p : kLowerPairs) { lf.push_back(p.from); lt.push_back(p.to); }
-  if ((rc = to_device(ix, lf.data(), lf.size(), &d.lower_from))) return rc;
-  if ((rc = to_device(ix, lt.data(), lt.size(), &d.lower_to))) return rc;
+  if ((rc = upload_description(ix, d))) return rc;
   if (!h.dups.empty()) {   // documents that repeat a term: side tables for the secondary-entry path
     const uint32_t S32 = h.n_segments;
     std::vector<uint32_t> dts, ddoc, dmult, ddocs, ets, ecnt;
@@ -1551,18 +1610,9 @@ int sg_index_upload(sg_index* ix, int device) {
     d.n_dups = (uint32_t)dts.size(); d.n_dup_docs = (uint32_t)ddocs.size(); d.n_extra = (uint32_t)ets.size();
   }
   d.slot_mask = (uint32_t)h.slots.size() - 1;
-  d.n_na = (uint32_t)h.sym.na_rune.size();
-  d.n_lower = (uint32_t)lf.size();
   d.S = h.n_segments;
   d.n_docs = (uint32_t)h.n_docs;
   d.n_terms = (uint32_t)h.term_key.size();
-  d.q = h.q;
-  d.n_wrap0 = (uint32_t)h.wrap0.size();
-  d.n_wrap1 = (uint32_t)h.wrap1.size();
-  for (size_t i = 0; i < h.wrap0.size(); i++) d.wrap0[i] = h.wrap0[i];
-  for (size_t i = 0; i < h.wrap1.size(); i++) d.wrap1[i] = h.wrap1[i];
-  d.n_pad = h.sym.n_pad;
-  memcpy(d.pad_sym, h.sym.pad_sym, 8);
   ix->device = device;
   const char* env = getenv("SG_LOG2_CNT");   // tuning knob: LDS counter words per wavefront (default 1024)
   if (env) { int v = atoi(env); if (v >= 9 && v <= 14) ix->log2_cnt = (uint32_t)v; }

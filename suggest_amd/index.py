@@ -47,7 +47,9 @@ def _c_desc(d):
 
 
 class NGramIndex:
-    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None):
+    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None, build="host"):
+        """build="host": sg_index_build (CPU tokenise + CSR); build="device": sg_index_build_device (same arrays, built on the
+        GPU `device`; documents with more than 128 n-grams are not supported there)."""
         L = _lib.lib()
         d = description or IndexDescription()
         self.description = d
@@ -63,7 +65,13 @@ class NGramIndex:
             self.n_docs = len(offs) - 1
             desc = _c_desc(d)
             h = C.c_void_p()
-            _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
+            if build == "device":
+                _lib.check(L.sg_index_build_device(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc),
+                                                   int(device), C.byref(h)))
+            elif build == "host":
+                _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
+            else:
+                raise ValueError("build must be 'host' or 'device'")
             self._h = h
         if upload:
             self.upload(device)
@@ -76,6 +84,12 @@ class NGramIndex:
         h = C.c_void_p()
         _lib.check(_lib.lib().sg_index_load_reference(_enc(hd_path), _enc(dl_path), C.byref(desc), C.byref(h)))
         return cls(description=description, device=device, upload=upload, _handle=h)
+
+    def digest(self):
+        """64-bit digests of the host CSR arrays (postings, seg_off, list lengths, term keys + repeated-term table)"""
+        out = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().sg_index_digest(self._h, out))
+        return tuple(int(x) for x in out)
 
     def upload(self, device=0):
         _lib.check(_lib.lib().sg_index_upload(self._h, int(device)))

@@ -376,3 +376,39 @@ def test_split_queries_match_unsplit(monkeypatch, cars_lines, words_lines):
     qb, qo = oracle.pack_strings(queries)
     assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.4, k=10),
                 ora.suggest_batch(qb, qo, "jaccard", 0.4, 10), queries)
+
+
+def test_device_index_build_is_identical_to_host_build(cars_lines, words_lines):
+    """the index built on the GPU (device tokeniser, device term table, radix sort) has the same CSR —
+    array for array (digests of postings, seg_off, list lengths, term numbering, repeated-term table) — as the host
+    build, for the reference's dictionaries (cars: 211 documents repeat a term; words), synthetic ones (q = 2, 3) and
+    awkward inputs (empty strings, non-ASCII, invalid UTF-8, strings shorter than q)."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    cases = [(cars_lines, _desc(CARS_DESC)), (words_lines, _desc(WORDS_DESC))]
+    for n, q, kw in ((200000, 3, {}), (50000, 2, {}), (100000, 3, dict(skewed=True, families=3))):
+        blob, offs = synth.make_dict(n, seed=41, **kw)
+        cases.append((synth.unpack(blob, offs), IndexDescription(**dict(synth.DESCRIPTION, ngram_size=q))))
+    odd = [b"", b"a", b"  ", "Привет мир".encode(), b"\xff\xfe bad \xc3", "İstanbul ǅ".encode(), b"ab", b"x" * 100, b"AAAAAAAA", b"abcabcabc"]
+    cases.append((odd * 7, IndexDescription(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "russian", "numbers", "$"))))
+    cases.append((odd * 3, IndexDescription(ngram_size=2, wrap=("^", "$"), pad="_", alphabet=("english", "_^$"))))
+    for docs, desc in cases:
+        host = NGramIndex(docs, desc, upload=False)
+        dev = NGramIndex(docs, desc, upload=False, build="device")
+        assert dev.stats() == host.stats()
+        assert dev.digest() == host.digest()
+    # and it searches like any other index
+    blob, offs = synth.make_dict(100000, seed=43)
+    qb, qo = synth.make_queries(512, blob, offs, seed=44)
+    dev = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION), build="device")
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **synth.DESCRIPTION)
+    assert_same(dev.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10), ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
+
+
+def test_device_index_build_rejects_documents_beyond_the_tokeniser():
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    import random
+    rnd = random.Random(5)
+    long_doc = bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(400))
+    with pytest.raises(Exception, match="sg_index_build"):
+        NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False, build="device")
+    NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False)      # the host builder takes it
