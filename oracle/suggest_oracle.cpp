@@ -20,7 +20,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <map>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -938,3 +940,5 @@ uint64_t or_query_algorithmic_bytes(const or_index* h, const uint8_t* q, int qle
 }
 
 }  // extern "C"
+
+#include "spell_oracle.inc"

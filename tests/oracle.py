@@ -21,8 +21,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "liboracle.so")
-        src = os.path.join(ROOT, "oracle", "suggest_oracle.cpp")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(ROOT, "oracle", n) for n in ("suggest_oracle.cpp", "spell_oracle.inc")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(x) for x in srcs):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
         L = C.CDLL(path)
         L.or_index_build.restype = C.c_void_p
@@ -54,6 +54,24 @@ def lib():
         L.or_autocomplete_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.or_query_algorithmic_bytes.restype = C.c_uint64
         L.or_query_algorithmic_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.or_lm_load.restype = C.c_void_p
+        L.or_lm_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.or_lm_free.argtypes = [C.c_void_p]
+        L.or_lm_words.restype = C.c_uint32
+        L.or_lm_words.argtypes = [C.c_void_p]
+        L.or_lm_word.restype = C.c_char_p
+        L.or_lm_word.argtypes = [C.c_void_p, C.c_uint32]
+        L.or_lm_word_id.restype = C.c_uint32
+        L.or_lm_word_id.argtypes = [C.c_void_p, C.c_char_p]
+        for f in (L.or_lm_score, L.or_lm_score_word_ids):
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for f in (L.or_lm_model_next_score, L.or_lm_next_score):
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_int)]
+        L.or_lm_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.or_spell_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_double,
+                                             C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -231,3 +249,64 @@ def metric_threshold(m, a, sa, sb):
 
 def metric_score(m, inter, sa, sb):
     return lib().or_metric_score(METRICS[m], inter, sa, sb)
+
+
+class OracleLM:
+    """or_lm_*: the language model of the spellchecker caller (pkg/lm), loaded from Google-format n-gram count files
+    <dir>/{1..order}-gm; word ids = line numbers of 1-gm."""
+
+    def __init__(self, directory, order, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-.")):
+        err = C.create_string_buffer(256)
+        self._h = lib().or_lm_load(_b(directory), int(order), _b(start_symbol), _b(end_symbol), b"\n".join(_b(a) for a in alphabet), err, 256)
+        if not self._h:
+            raise IOError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().or_lm_free(self._h)
+            self._h = None
+
+    def words(self):
+        L = lib()
+        return [L.or_lm_word(self._h, i) for i in range(L.or_lm_words(self._h))]
+
+    def word_id(self, w):
+        return int(lib().or_lm_word_id(self._h, _b(w)))
+
+    def _ids(self, words):
+        return np.array([self.word_id(w) for w in words], dtype=np.uint32)
+
+    def score(self, words):
+        """NGramModel.Score over the ids of `words` (ngram_model.go:44-62)"""
+        ids = self._ids(words)
+        return float(lib().or_lm_score(self._h, ids.ctypes.data, len(ids)))
+
+    def score_sentence(self, words):
+        """LanguageModel.ScoreSentence (language_model.go:66-86)"""
+        ids = self._ids(words)
+        return float(lib().or_lm_score_word_ids(self._h, ids.ctypes.data, len(ids)))
+
+    def next_score(self, context, word, model_level=False):
+        """Next(context).ScoreNext(word): (status, score); status 0 scorer / 1 nil scorer / 2 error"""
+        ids = self._ids(context)
+        st = C.c_int(0)
+        f = lib().or_lm_model_next_score if model_level else lib().or_lm_next_score
+        v = f(self._h, ids.ctypes.data, len(ids), self.word_id(word), C.byref(st))
+        return st.value, float(v)
+
+    def tokenize(self, text):
+        raw = _b(text)
+        buf = C.create_string_buffer(len(raw) * 2 + 64)
+        n = lib().or_lm_tokenize(self._h, raw, len(raw), buf, len(buf))
+        return buf.value.split(b"\n") if n else []
+
+    def predict_batch(self, index, blob, offs, top_k, similarity, threads=0):
+        """SpellChecker.Predict per query -> (ids [n, top_k+1], counts [n]); `index` is an OracleIndex over self.words()"""
+        n = len(offs) - 1
+        ids = np.zeros((n, top_k + 1), dtype=np.uint32)
+        cnt = np.zeros(n, dtype=np.uint32)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lib().or_spell_predict_batch(index._h, self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n, int(top_k),
+                                     float(similarity), ids.ctypes.data, cnt.ctypes.data, threads or (os.cpu_count() or 1))
+        return ids, cnt

@@ -109,6 +109,12 @@ def main():
         shutil.copyfile(os.path.join(REF, "db", name), os.path.join(OUT, "db", name))
     for name in ("cars.dict", "config.json", "db/cars.hd", "db/cars.dl", "db/cars.cdb"):
         os.chmod(os.path.join(OUT, name), 0o644)
+    # pkg/lm/testdata/fixtures: the Google-format n-gram count files the reference's LM tests read (data, not source)
+    os.makedirs(os.path.join(OUT, "lm"), exist_ok=True)
+    LM_REF = os.path.join(os.path.dirname(REF), "..", "lm", "testdata", "fixtures")
+    for name in ("1-gm", "2-gm", "3-gm"):
+        shutil.copyfile(os.path.join(LM_REF, name), os.path.join(OUT, "lm", name))
+        os.chmod(os.path.join(OUT, "lm", name), 0o644)
     write_words_subset()
     with open(os.path.join(REF, "words.dict"), "rb") as f:
         raw = f.read()
