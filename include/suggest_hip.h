@@ -54,6 +54,7 @@ enum sg_error {
 #define SG_COUNT_REF_PANIC 0xFFFFFFFFu     /* reference: make(chan, negative) panics */
 #define SG_COUNT_REF_DEADLOCK 0xFFFFFFFEu  /* reference: capacity-0 channel, send blocks forever */
 #define SG_COUNT_TOO_LONG 0xFFFFFFFDu      /* more than SG_MAX_QUERY_TERMS n-grams */
+#define SG_COUNT_LM_ERROR 0xFFFFFFFCu       /* LanguageModel.Next returned an error (sg_spell_predict_batch) */
 #define SG_MAX_QUERY_TERMS 128u
 #define SG_MAX_TOPK 1024u
 
@@ -107,6 +108,41 @@ void sg_index_retain(sg_index* index);
 void sg_index_release(sg_index* index);
 
 const char* sg_last_error(void);
+
+/* ---- the spellchecker caller of the path --------------------------------------
+ * pkg/lm: n-gram language model with stupid backoff; pkg/spellchecker: SpellChecker.Predict. */
+typedef struct sg_lm sg_lm;
+
+/* NewGoogleNGramReader(order, indexer, dir).Read + NewLanguageModel (pkg/lm/ngram_reader.go:38-98, indexer.go:86-114,
+ * language_model.go:24-49): <dir>/1-gm .. <dir>/<order>-gm hold "w1 .. wk\tcount" lines; word ids are the line numbers
+ * of 1-gm; `alphabet` is the words alphabet of the lm config (pkg/lm/config.go:25-27) used by the query tokenizer. */
+int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol,
+                      const char* const* alphabet, uint32_t n_alphabet, sg_lm** out);
+void sg_lm_retain(sg_lm* lm);
+void sg_lm_release(sg_lm* lm);
+uint32_t sg_lm_num_words(const sg_lm* lm);
+int sg_lm_word(const sg_lm* lm, uint32_t id, char* out, uint32_t cap);             /* Indexer.Find; returns the length */
+uint32_t sg_lm_word_id(const sg_lm* lm, const uint8_t* word, uint32_t len);          /* Indexer.Get; 0xFFFFFFFF = unknown */
+double sg_lm_score(const sg_lm* lm, const uint32_t* ids, uint32_t n);                /* NGramModel.Score, ngram_model.go:44-62 */
+double sg_lm_score_word_ids(const sg_lm* lm, const uint32_t* ids, uint32_t n);       /* LanguageModel.ScoreWordIDs, language_model.go:78-86 */
+/* Next(context).ScoreNext(word): returns 0 (score written), 1 (nil scorer) or 2 (error); model_level != 0 calls
+ * NGramModel.Next (ngram_model.go:64-98) instead of LanguageModel.Next (language_model.go:100-112). */
+int sg_lm_next_score(const sg_lm* lm, const uint32_t* context, uint32_t n, uint32_t word, int model_level, double* score);
+/* lm.NewTokenizer(alphabet).Tokenize (pkg/lm/tokenizer.go:26-31): tokens joined by '\n' into out; returns their number */
+int sg_lm_tokenize(const sg_lm* lm, const uint8_t* text, uint32_t len, char* out, uint32_t cap);
+
+/* The fuzzy index of the spellchecker: built over the model's vocabulary (docID = word id) and uploaded —
+ * internal/spellchecker/dep/spellchecker.go:33-45 (NewRAMBuilder over the LM dictionary). */
+int sg_spell_index_build(const sg_lm* lm, const sg_desc* desc, int device, sg_index** out);
+
+/* SpellChecker.Predict (pkg/spellchecker/spellchecker.go:40-92) for a batch of queries: the last word of a query is
+ * completed (Autocomplete with the LM collector, collector.go / scorer.go: top_k by ScoreNext of the preceding words),
+ * topped up by the Cosine fuzzy search when fewer than top_k complete it, re-ranked by ScoreNext (stable) and cut to
+ * top_k + 1 entries (sic, :87-89).  Row i of out_ids (top_k + 1 word ids) holds the prediction of query i,
+ * out_counts[i] how many (or SG_COUNT_REF_PANIC / _DEADLOCK / _TOO_LONG / _LM_ERROR).  `index` must come from
+ * sg_spell_index_build (or be any uploaded index over the model's vocabulary in id order). */
+int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                           uint32_t top_k, double similarity, uint32_t* out_ids, uint32_t* out_counts);
 
 /* ---- introspection (tests, bench.py) ---------------------------------------------------- */
 typedef struct sg_stats {

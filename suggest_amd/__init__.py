@@ -5,3 +5,4 @@ Host mirror of the reference's pkg/suggest API over libsuggest_hip.so (hand-writ
 from .index import IndexDescription, NGramIndex, pack_strings  # noqa: F401
 from .metric import CosineMetric, DiceMetric, ExactMetric, JaccardMetric, OverlapMetric  # noqa: F401
 from .service import ResultItem, SearchConfig, Service, read_configs, read_dictionary  # noqa: F401
+from .spell import LanguageModel, SpellChecker  # noqa: F401

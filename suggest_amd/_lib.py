@@ -20,7 +20,10 @@ EXPORTS = [
     "sg_index_build", "sg_index_build_device", "sg_index_digest", "sg_index_load_reference", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
     "sg_autocomplete_batch_device", "sg_index_retain", "sg_index_release", "sg_last_error", "sg_index_stats",
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
+    "sg_lm_load_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
+    "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch",
 ]
+SG_COUNT_LM_ERROR = 0xFFFFFFFC
 
 
 class SgDesc(C.Structure):
@@ -60,6 +63,23 @@ def lib():
     L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
     L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+    L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    L.sg_lm_retain.argtypes = [vp]
+    L.sg_lm_retain.restype = None
+    L.sg_lm_release.argtypes = [vp]
+    L.sg_lm_release.restype = None
+    L.sg_lm_num_words.argtypes = [vp]
+    L.sg_lm_num_words.restype = u32
+    L.sg_lm_word.argtypes = [vp, u32, C.c_char_p, u32]
+    L.sg_lm_word_id.argtypes = [vp, C.c_char_p, u32]
+    L.sg_lm_word_id.restype = u32
+    for f in (L.sg_lm_score, L.sg_lm_score_word_ids):
+        f.argtypes = [vp, vp, u32]
+        f.restype = dbl
+    L.sg_lm_next_score.argtypes = [vp, vp, u32, u32, i32, C.POINTER(dbl)]
+    L.sg_lm_tokenize.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32]
+    L.sg_spell_index_build.argtypes = [vp, C.POINTER(SgDesc), i32, C.POINTER(vp)]
+    L.sg_spell_predict_batch.argtypes = [vp, vp, vp, vp, u32, u32, dbl, vp, vp]
     L.sg_index_retain.argtypes = [vp]
     L.sg_index_retain.restype = None
     L.sg_index_release.argtypes = [vp]

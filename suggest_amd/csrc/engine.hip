@@ -90,6 +90,10 @@ struct BatchArgs {
   uint32_t item_cap, slot_cap;
   uint32_t split_chunks;  // 16-byte chunks of postings per part of a split query ...
   uint32_t split_min;     // ... which is a query (tile) whose admissible lists hold at least this many
+  // ---- spellchecker mode of autocomplete: candidates ranked by the language model ----
+  const uint64_t* lm_values;   // word << 32 | count of every n-gram level, flattened; null: plain autocomplete
+  const uint32_t* lm_from;     // [n_q] the continuations of query i's context are lm_values[lm_from[i] .. lm_to[i])
+  const uint32_t* lm_to;       //       (sorted by word; from == to: no scorer, every candidate scores alike)
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -225,6 +229,25 @@ __device__ uint32_t d_term_lookup(const DeviceIndex& ix, uint64_t key) {
     if (s.key == key) return s.term;
     h = (h + 1) & ix.slot_mask;
   }
+}
+
+// count of `word` among the continuations values[from .. to) of a context (sorted by word): a 64-ary search, one probe
+// per lane and round (scorerNext.ScoreNext, pkg/lm/scorer_next.go:15-23: the score is monotone in this count).
+__device__ uint32_t d_lm_count(const uint64_t* values, uint32_t from, uint32_t to, uint32_t word, int lane) {
+  while (to - from > 64u) {
+    const uint32_t step = (to - from + 63u) >> 6, pos = from + (uint32_t)lane * step;
+    const uint32_t w = pos < to ? (uint32_t)(values[pos] >> 32) : 0xFFFFFFFFu;
+    const uint64_t m = ballot(pos < to && w <= word);          // a prefix of the lanes
+    if (!m) return 0u;
+    const uint32_t at = popc64(m) - 1u;
+    from += at * step;
+    to = min(to, from + step);
+  }
+  const uint32_t pos = from + (uint32_t)lane;
+  const uint64_t v = pos < to ? values[pos] : ~0ull;
+  const uint64_t m = ballot(pos < to && (uint32_t)(v >> 32) == word);
+  if (!m) return 0u;
+  return readlane((uint32_t)v, __builtin_ctzll(m));
 }
 
 // Tokeniser: wrap -> lower -> trim -> q-grams (first-occurrence dedup) -> normalise -> term ids.
@@ -690,6 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
   do {   // one query (or one part of one): `break` leaves it
   const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
+  const uint32_t lm_from = a.lm_values ? a.lm_from[qi] : 0u, lm_to = a.lm_values ? a.lm_to[qi] : 0u;
   uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
@@ -807,7 +831,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     //      verified together (their binary searches overlap in flight) instead of stalling the stream ----
     uint32_t qn = 0;
     auto offer = [&](uint32_t d, int overlap, int w) {
-      if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);         // score = -docID, collector.go:104-106
+      if (a.autocomplete && a.lm_values)                                    // lmCollector: score = ScoreNext(doc), monotone in the count
+        topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
+      else if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);     // score = -docID, collector.go:104-106
       else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
     };
     auto emit_secondaries = [&](uint32_t d, int w, int T, uint64_t fm0, uint64_t fm1) {
@@ -1356,6 +1382,15 @@ struct sg_index {
     }                                                                                   \
   } while (0)
 
+struct sg_lm {
+  HostLM host;
+  std::atomic<int> refs{1};
+  std::mutex mu;                       // guards the lazy upload
+  int device = -1;
+  uint64_t* d_values = nullptr;        // every level's (word << 32 | count), level after level
+  std::vector<uint32_t> level_base;    // first entry of level l in d_values
+};
+
 static void* g_prof_buf = nullptr;   // SG_PHASE_TIMING builds only (sg_debug_set_prof)
 
 namespace {
@@ -1420,11 +1455,14 @@ int check_search_args(sg_index* index, uint32_t k, bool need_alpha, double simil
   return SG_OK;
 }
 
+struct LmRanges { const uint64_t* values; const uint32_t *from, *to; };   // device pointers (spellchecker mode)
+
 int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, int metric, double similarity, uint32_t k,
-           int autocomplete, void* d_ids, void* d_scores, void* d_counts, hipStream_t stream) {
+           int autocomplete, void* d_ids, void* d_scores, void* d_counts, hipStream_t stream, const LmRanges* lm = nullptr) {
   if (n_q == 0) return SG_OK;
   BatchArgs a{};
   a.ix = index->dix;
+  if (lm) { a.lm_values = lm->values; a.lm_from = lm->from; a.lm_to = lm->to; }
   a.q_blob = (const uint8_t*)d_q;
   a.q_offs = (const uint64_t*)d_offs;
   a.out_ids = (uint32_t*)d_ids;
@@ -1715,6 +1753,211 @@ int sg_autocomplete_batch(sg_index* index, const uint8_t* q, const uint64_t* off
   if (rc) return rc;
   if (!offs || !ids || !counts) { set_error("null argument"); return SG_E_INVALID; }
   return run_host(index, q, offs, n_q, 0, 0, limit, 1, ids, nullptr, counts);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// language model + SpellChecker.Predict
+// ------------------------------------------------------------------------------------------
+int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const char* const* alphabet,
+                      uint32_t n_alphabet, sg_lm** out) {
+  if (!dir || !out) { set_error("null argument"); return SG_E_INVALID; }
+  auto* lm = new (std::nothrow) sg_lm();
+  if (!lm) return SG_E_NOMEM;
+  std::vector<std::string> alpha;
+  for (uint32_t i = 0; i < n_alphabet; i++) alpha.emplace_back(alphabet[i]);
+  std::string err;
+  int rc;
+  try {
+    rc = lm_load_google(dir, order, start_symbol, end_symbol, alpha, lm->host, err);
+  } catch (const std::exception& e) {
+    err = e.what(); rc = SG_E_INVALID;
+  }
+  if (rc) { set_error(err); delete lm; return rc; }
+  *out = lm;
+  return SG_OK;
+}
+
+void sg_lm_retain(sg_lm* lm) { if (lm) lm->refs.fetch_add(1); }
+void sg_lm_release(sg_lm* lm) {
+  if (!lm || lm->refs.fetch_sub(1) != 1) return;
+  if (lm->d_values) { (void)hipSetDevice(lm->device); (void)hipFree(lm->d_values); }
+  delete lm;
+}
+uint32_t sg_lm_num_words(const sg_lm* lm) { return lm ? (uint32_t)lm->host.words.size() : 0u; }
+int sg_lm_word(const sg_lm* lm, uint32_t id, char* out, uint32_t cap) {
+  if (!lm || id >= lm->host.words.size()) { set_error("no such word id"); return SG_E_INVALID; }
+  const std::string& w = lm->host.words[id];
+  if (w.size() <= cap) memcpy(out, w.data(), w.size());
+  return (int)w.size();
+}
+uint32_t sg_lm_word_id(const sg_lm* lm, const uint8_t* word, uint32_t len) {
+  return lm ? lm_word_id(lm->host, std::string((const char*)word, len)) : kUnknownWord;
+}
+double sg_lm_score(const sg_lm* lm, const uint32_t* ids, uint32_t n) { return lm_model_score(lm->host, ids, n); }
+double sg_lm_score_word_ids(const sg_lm* lm, const uint32_t* ids, uint32_t n) { return lm_score_word_ids(lm->host, ids, n); }
+int sg_lm_next_score(const sg_lm* lm, const uint32_t* context, uint32_t n, uint32_t word, int model_level, double* score) {
+  const LmNext nx = model_level ? lm_model_next(lm->host, context, n) : lm_next(lm->host, context, n);
+  if (score) *score = nx.status ? 0.0 : lm_next_score(lm->host, nx, word);
+  return nx.status;
+}
+int sg_lm_tokenize(const sg_lm* lm, const uint8_t* text, uint32_t len, char* out, uint32_t cap) {
+  std::vector<std::string> toks;
+  lm_tokenize(lm->host, text, len, toks);
+  std::string joined;
+  for (size_t i = 0; i < toks.size(); i++) { if (i) joined.push_back('\n'); joined += toks[i]; }
+  if (joined.size() < cap) { memcpy(out, joined.data(), joined.size()); out[joined.size()] = 0; }
+  return (int)toks.size();
+}
+
+int sg_spell_index_build(const sg_lm* lm, const sg_desc* desc, int device, sg_index** out) {
+  if (!lm || !out) { set_error("null argument"); return SG_E_INVALID; }
+  std::string blob;
+  std::vector<uint64_t> offs(1, 0);
+  for (const auto& w : lm->host.words) { blob += w; offs.push_back(blob.size()); }   // docID = word id
+  int rc = sg_index_build((const uint8_t*)blob.data(), offs.data(), (uint32_t)lm->host.words.size(), desc, out);
+  if (rc) return rc;
+  rc = sg_index_upload(*out, device);
+  if (rc) { sg_index_release(*out); *out = nullptr; }
+  return rc;
+}
+
+static int lm_upload(sg_lm* lm, int device) {
+  std::lock_guard<std::mutex> lock(lm->mu);
+  if (lm->d_values) {
+    if (lm->device != device) { set_error("language model already resident on another device"); return SG_E_INVALID; }
+    return SG_OK;
+  }
+  std::vector<uint64_t> flat;
+  for (const LmLevel& lv : lm->host.level) {
+    lm->level_base.push_back((uint32_t)flat.size());
+    for (size_t i = 0; i < lv.word.size(); i++) flat.push_back(((uint64_t)lv.word[i] << 32) | lv.count[i]);
+  }
+  if (flat.size() >= 0xFFFFFFF0ull) { set_error("language model too large"); return SG_E_UNSUPPORTED; }
+  HIP_TRY(hipSetDevice(device));
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, std::max<size_t>(flat.size() * 8, 16)));
+  if (!flat.empty()) HIP_TRY(hipMemcpy(p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice));
+  lm->d_values = (uint64_t*)p;
+  lm->device = device;
+  return SG_OK;
+}
+
+// SpellChecker.Predict (pkg/spellchecker/spellchecker.go:40-92) for a batch.  Host: word tokeniser, word ids, Next
+// (a handful of binary searches per query).  GPU: Autocomplete with the LM collector for every query in one launch
+// (top-k by ScoreNext = by the continuation count), then the Cosine fuzzy search for the queries that got fewer than
+// topK.  Host again: merge, stable sort by ScoreNext, candidates[:topK+1] (sic).
+int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t top_k,
+                           double similarity, uint32_t* out_ids, uint32_t* out_counts) {
+  int rc = check_search_args(index, top_k, true, similarity, SG_COSINE);
+  if (rc) return rc;
+  if (!lm || !q_offs || !out_ids || !out_counts) { set_error("null argument"); return SG_E_INVALID; }
+  if (top_k + 1 > SG_MAX_TOPK) { set_error("topK above SG_MAX_TOPK - 1"); return SG_E_INVALID; }
+  if (n_q == 0) return SG_OK;
+  if ((rc = lm_upload(lm, index->device))) return rc;
+  const HostLM& h = lm->host;
+  const size_t row = (size_t)top_k + 1;
+
+  // ---- host: last word + the continuations of its context ----
+  std::vector<LmNext> next(n_q);
+  std::vector<uint8_t> has_word(n_q, 0);
+  std::string words;
+  std::vector<uint64_t> w_offs(1, 0);
+  std::vector<uint32_t> lm_from(n_q, 0), lm_to(n_q, 0);
+  std::vector<std::string> toks;
+  std::vector<uint32_t> ids;
+  for (uint32_t i = 0; i < n_q; i++) {
+    out_counts[i] = 0;
+    lm_tokenize(h, q_utf8 + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i]), toks);
+    next[i].status = 1;
+    if (!toks.empty()) {
+      has_word[i] = 1;
+      words += toks.back();
+      ids.clear();
+      for (size_t t = 0; t + 1 < toks.size(); t++) ids.push_back(lm_word_id(h, toks[t]));
+      if (!ids.empty()) {                                       // spellchecker.go:94-107
+        next[i] = lm_next(h, ids.data(), ids.size());
+        if (next[i].status == 0) { lm_from[i] = lm->level_base[next[i].level] + next[i].from; lm_to[i] = lm->level_base[next[i].level] + next[i].to; }
+      }
+    }
+    w_offs.push_back(words.size());
+  }
+
+  // ---- GPU: LM-ranked autocomplete of every last word ----
+  HIP_TRY(hipSetDevice(index->device));
+  hipStream_t st;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  std::vector<void*> dev;
+  auto cleanup = [&]() { for (void* p : dev) (void)hipFree(p); (void)hipStreamDestroy(st); };
+#define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return SG_E_HIP; } } while (0)
+  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e == hipSuccess) dev.push_back(*p); return e; };
+  void *dq, *doffs, *dfrom, *dto, *dids, *dcnt;
+  TRY3(dalloc(&dq, words.size())); TRY3(dalloc(&doffs, (size_t)(n_q + 1) * 8)); TRY3(dalloc(&dfrom, (size_t)n_q * 4));
+  TRY3(dalloc(&dto, (size_t)n_q * 4)); TRY3(dalloc(&dids, (size_t)n_q * top_k * 4)); TRY3(dalloc(&dcnt, (size_t)n_q * 4));
+  if (!words.empty()) TRY3(hipMemcpyAsync(dq, words.data(), words.size(), hipMemcpyHostToDevice, st));
+  TRY3(hipMemcpyAsync(doffs, w_offs.data(), (size_t)(n_q + 1) * 8, hipMemcpyHostToDevice, st));
+  TRY3(hipMemcpyAsync(dfrom, lm_from.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, st));
+  TRY3(hipMemcpyAsync(dto, lm_to.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, st));
+  TRY3(hipMemsetAsync(dids, 0, (size_t)n_q * top_k * 4, st));
+  const LmRanges ranges{lm->d_values, (const uint32_t*)dfrom, (const uint32_t*)dto};
+  rc = launch(index, dq, doffs, n_q, 0, 0, top_k, 1, dids, nullptr, dcnt, st, &ranges);
+  if (rc) { cleanup(); return rc; }
+  std::vector<uint32_t> a_ids((size_t)n_q * top_k), a_cnt(n_q);
+  TRY3(hipMemcpyAsync(a_ids.data(), dids, a_ids.size() * 4, hipMemcpyDeviceToHost, st));
+  TRY3(hipMemcpyAsync(a_cnt.data(), dcnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, st));
+  TRY3(hipStreamSynchronize(st));
+
+  // ---- GPU: fuzzy search (Cosine) for the queries whose completion list is short ----
+  std::vector<uint32_t> need;
+  for (uint32_t i = 0; i < n_q; i++) {
+    if (a_cnt[i] == SG_COUNT_TOO_LONG) { out_counts[i] = SG_COUNT_TOO_LONG; continue; }
+    if (has_word[i] && a_cnt[i] < top_k) need.push_back(i);
+  }
+  std::vector<uint32_t> f_ids, f_cnt;
+  if (!need.empty()) {
+    std::string fw;
+    std::vector<uint64_t> f_offs(1, 0);
+    for (uint32_t i : need) { fw.append(words, (size_t)w_offs[i], (size_t)(w_offs[i + 1] - w_offs[i])); f_offs.push_back(fw.size()); }
+    const uint32_t n_f = (uint32_t)need.size();
+    void *fq, *fo, *fi, *fs, *fc;
+    TRY3(dalloc(&fq, fw.size())); TRY3(dalloc(&fo, (size_t)(n_f + 1) * 8)); TRY3(dalloc(&fi, (size_t)n_f * top_k * 4));
+    TRY3(dalloc(&fs, (size_t)n_f * top_k * 8)); TRY3(dalloc(&fc, (size_t)n_f * 4));
+    if (!fw.empty()) TRY3(hipMemcpyAsync(fq, fw.data(), fw.size(), hipMemcpyHostToDevice, st));
+    TRY3(hipMemcpyAsync(fo, f_offs.data(), (size_t)(n_f + 1) * 8, hipMemcpyHostToDevice, st));
+    TRY3(hipMemsetAsync(fi, 0, (size_t)n_f * top_k * 4, st));
+    rc = launch(index, fq, fo, n_f, SG_COSINE, similarity, top_k, 0, fi, fs, fc, st);
+    if (rc) { cleanup(); return rc; }
+    f_ids.resize((size_t)n_f * top_k); f_cnt.resize(n_f);
+    TRY3(hipMemcpyAsync(f_ids.data(), fi, f_ids.size() * 4, hipMemcpyDeviceToHost, st));
+    TRY3(hipMemcpyAsync(f_cnt.data(), fc, (size_t)n_f * 4, hipMemcpyDeviceToHost, st));
+    TRY3(hipStreamSynchronize(st));
+  }
+#undef TRY3
+  cleanup();
+
+  // ---- host: merge, re-rank, truncate ----
+  std::vector<uint32_t> fuzzy_of(n_q, 0xFFFFFFFFu);
+  for (size_t j = 0; j < need.size(); j++) fuzzy_of[need[j]] = (uint32_t)j;
+  std::vector<uint32_t> cands;
+  for (uint32_t i = 0; i < n_q; i++) {
+    if (out_counts[i] == SG_COUNT_TOO_LONG || !has_word[i]) continue;
+    if (next[i].status == 2) { out_counts[i] = SG_COUNT_LM_ERROR; continue; }
+    cands.assign(a_ids.begin() + (size_t)i * top_k, a_ids.begin() + (size_t)i * top_k + a_cnt[i]);
+    if (fuzzy_of[i] != 0xFFFFFFFFu) {
+      const uint32_t j = fuzzy_of[i], c = f_cnt[j];
+      if (c >= SG_COUNT_TOO_LONG) { out_counts[i] = c; continue; }       // the reference panics / dead-locks here (suggester.go:62)
+      for (uint32_t x = 0; x < c; x++) {                                   // merge — spellchecker.go:133-150
+        const uint32_t y = f_ids[(size_t)j * top_k + x];
+        if (std::find(cands.begin(), cands.end(), y) == cands.end()) cands.push_back(y);
+      }
+    }
+    if (next[i].status == 0)                                               // sort.SliceStable by ScoreNext desc (monotone in the count)
+      std::stable_sort(cands.begin(), cands.end(), [&](uint32_t x, uint32_t y) { return lm_next_count(h, next[i], x) > lm_next_count(h, next[i], y); });
+    if (top_k < cands.size()) cands.resize(row);                           // candidates[:topK+1] (sic)
+    out_counts[i] = (uint32_t)cands.size();
+    std::copy(cands.begin(), cands.end(), out_ids + (size_t)i * row);
+  }
+  return SG_OK;
 }
 
 #ifdef SG_PHASE_TIMING

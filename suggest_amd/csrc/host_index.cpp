@@ -143,6 +143,15 @@ int build_symbols(HostIndex& ix, std::string& err) {
 
 }  // namespace
 
+// text helpers shared with lm.cpp (same decoding / lower-casing rules as the index tokeniser)
+uint32_t host_next_rune(const uint8_t* s, size_t n, size_t* adv) { return next_rune(s, n, adv); }
+uint32_t host_lower_rune(uint32_t r) { return lower_rune(r); }
+uint32_t host_utf8_width(uint32_t r) { return utf8_width(r); }
+bool host_alphabet_has(const std::vector<std::string>& spec, uint32_t r) {
+  for (const auto& part : spec) if (alphabet_part_has(part, r)) return true;
+  return false;
+}
+
 uint64_t mix64(uint64_t k) {  // splitmix64 finaliser
   k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
   k ^= k >> 27; k *= 0x94D049BB133111EBull;

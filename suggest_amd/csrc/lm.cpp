@@ -1,0 +1,202 @@
+// lm.cpp — host side of the spellchecker caller's language model: n-gram counts with stupid backoff.
+//
+// What it mirrors (behaviour; the layout is this project's own):
+//   pkg/lm/ngram_reader.go:38-98        Google n-gram format: <dir>/<k>-gm, lines "w1 .. wk\tcount"
+//   pkg/lm/indexer.go:50-114            word ids = line numbers of 1-gm; unknown word = 0xFFFFFFFF
+//   pkg/lm/ngram_vector_builder.go + packed_array.go   counts keyed by (parent offset, word), repeated lines accumulate
+//   pkg/lm/ngram_model.go:44-98,163-175 Score / Next / calcScore (alpha = 0.4, unknown = -100)
+//   pkg/lm/language_model.go:78-112     ScoreWordIDs, Next (wrap / trim rules)
+//   pkg/lm/tokenizer.go + pkg/analysis/word_tokenizer.go
+// Layout: one LmLevel per order, entries sorted by (parent, word); instead of the reference's binary-searched list of
+// (context, from) containers the children of parent p are child_begin[p] .. child_begin[p+1] — a direct index, which is
+// also what the GPU kernel gets (a [from, to) range per query into one flat array of word<<32|count).
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <map>
+
+#include "sg_internal.h"
+
+namespace sg {
+
+namespace {
+
+// entry of `word` under parent `parent` (an offset into the previous level, or kNoContext): its offset or kNoContext
+uint32_t level_find(const LmLevel& lv, uint32_t n_parents, uint32_t word, uint32_t parent) {
+  uint32_t bucket;
+  if (parent == kNoContext) bucket = n_parents;
+  else if (parent < n_parents) bucket = parent;
+  else return kNoContext;
+  const uint32_t from = lv.child_begin[bucket], to = lv.child_begin[bucket + 1];
+  const auto b = lv.word.begin();
+  const auto it = std::lower_bound(b + from, b + to, word);
+  if (it == b + to || *it != word) return kNoContext;
+  return (uint32_t)(it - b);
+}
+
+uint32_t parents_of(const HostLM& lm, size_t level) { return level == 0 ? 0u : (uint32_t)lm.level[level - 1].word.size(); }
+
+double calc_score(const uint32_t* counts, size_t n) {   // ngram_model.go:163-175; counts[0] may be the corpus total
+  double factor = 1;
+  for (size_t i = n - 1; i >= 1; i--) {
+    if (counts[i] > 0) return std::log(factor * (double)counts[i] / (double)counts[i - 1]);
+    factor *= 0.4;
+  }
+  return -100.0;
+}
+
+}  // namespace
+
+uint32_t lm_word_id(const HostLM& lm, const std::string& token) {
+  auto it = lm.id_of.find(token);
+  return it == lm.id_of.end() ? kUnknownWord : it->second;
+}
+
+int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const std::vector<std::string>& alphabet,
+                   HostLM& lm, std::string& err) {
+  if (order < 1 || order > 8) { err = "nGramOrder should be >= 1"; return SG_E_INVALID; }
+  lm.order = order;
+  lm.alphabet = alphabet;
+  {
+    std::ifstream f(std::string(dir) + "/1-gm");
+    if (!f) { err = std::string("failed to open ") + dir + "/1-gm"; return SG_E_INVALID; }
+    std::string line;
+    while (std::getline(f, line)) {
+      const std::string w = line.substr(0, line.find('\t'));
+      lm.id_of.emplace(w, (uint32_t)lm.words.size());
+      lm.words.push_back(w);
+    }
+  }
+  for (uint32_t k = 1; k <= order; k++) {
+    std::ifstream f(std::string(dir) + "/" + std::to_string(k) + "-gm");
+    if (!f) { err = "failed to open a ngram input: " + std::to_string(k) + "-gm"; return SG_E_INVALID; }
+    std::map<std::pair<uint32_t, uint32_t>, uint64_t> acc;   // (parent, word) -> count; kNoContext sorts last
+    std::string line;
+    std::vector<uint32_t> ids;
+    while (std::getline(f, line)) {
+      const size_t tab = line.find('\t');
+      if (tab == std::string::npos) { err = "ngram file is corrupted, expected number"; return SG_E_INVALID; }
+      ids.clear();
+      for (size_t p = 0;;) {
+        const size_t sp = line.find(' ', p);
+        const size_t end = (sp == std::string::npos || sp > tab) ? tab : sp;
+        ids.push_back(lm_word_id(lm, line.substr(p, end - p)));
+        if (end == tab) break;
+        p = end + 1;
+      }
+      if (ids.size() != k) { err = "failed to add nGrams to a builder: nGrams order is out of range"; return SG_E_INVALID; }
+      uint32_t parent = kNoContext;
+      for (uint32_t i = 0; i + 1 < k; i++) parent = level_find(lm.level[i], parents_of(lm, i), ids[i], parent);
+      char* endp = nullptr;
+      const unsigned long long c = strtoull(line.c_str() + tab + 1, &endp, 10);
+      if (endp == line.c_str() + tab + 1) { err = "ngram file is corrupted, expected number"; return SG_E_INVALID; }
+      acc[{parent, ids.back()}] += c;
+    }
+    LmLevel lv;
+    const uint32_t n_parents = parents_of(lm, k - 1);
+    lv.child_begin.assign((size_t)n_parents + 2, 0);
+    for (const auto& kv : acc) {
+      const uint32_t bucket = kv.first.first == kNoContext ? n_parents : kv.first.first;
+      lv.child_begin[bucket + 1]++;
+      lv.word.push_back(kv.first.second);
+      lv.count.push_back((uint32_t)kv.second);
+      lv.total = (uint32_t)(lv.total + kv.second);           // WordCount is uint32: wraps like the reference's
+    }
+    for (size_t b = 0; b + 1 < lv.child_begin.size(); b++) lv.child_begin[b + 1] += lv.child_begin[b];
+    lm.level.push_back(std::move(lv));
+  }
+  lm.start_symbol = lm_word_id(lm, start_symbol ? start_symbol : "");
+  lm.end_symbol = lm_word_id(lm, end_symbol ? end_symbol : "");
+  return SG_OK;
+}
+
+double lm_model_score(const HostLM& lm, const uint32_t* ids, size_t n) {   // NGramModel.Score
+  const size_t order = std::min<size_t>(lm.order, n);
+  uint32_t counts[10] = {0};
+  uint32_t parent = kNoContext;
+  for (size_t i = 0; i < order; i++) {
+    if (i == 0) counts[0] = (uint32_t)lm.level[0].total;
+    const uint32_t at = level_find(lm.level[i], parents_of(lm, i), ids[i], parent);
+    counts[i + 1] = at == kNoContext ? 0u : lm.level[i].count[at];
+    parent = at;
+  }
+  return calc_score(counts, order + 1);
+}
+
+double lm_score_word_ids(const HostLM& lm, const uint32_t* ids, size_t n) {   // LanguageModel.ScoreWordIDs
+  std::vector<uint32_t> seq;
+  seq.push_back(lm.start_symbol);
+  seq.insert(seq.end(), ids, ids + n);
+  seq.push_back(lm.end_symbol);
+  double score = 0;
+  for (size_t i = 0; i + lm.order <= seq.size(); i++) score += lm_model_score(lm, seq.data() + i, lm.order);
+  return score;
+}
+
+LmNext lm_model_next(const HostLM& lm, const uint32_t* ids, size_t n) {   // NGramModel.Next
+  LmNext nx;
+  if (lm.order <= n || n == 0) { nx.status = 2; return nx; }   // "nGrams length should be less than the nGramModel order"
+  uint32_t parent = kNoContext;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t at = level_find(lm.level[i], parents_of(lm, i), ids[i], parent);
+    if (at == kNoContext || lm.level[i].count[at] == 0) { nx.status = 1; return nx; }
+    nx.context_count = lm.level[i].count[at];
+    parent = at;
+  }
+  const LmLevel& lv = lm.level[n];
+  nx.level = (uint32_t)n;
+  nx.from = lv.child_begin[parent];
+  nx.to = lv.child_begin[parent + 1];
+  if (nx.from == nx.to) nx.status = 1;                          // SubVector(parent) == nil
+  return nx;
+}
+
+LmNext lm_next(const HostLM& lm, const uint32_t* ids, size_t n) {   // LanguageModel.Next
+  std::vector<uint32_t> seq(ids, ids + n);
+  const size_t N = lm.order;
+  if (seq.size() + 1 < N) seq.insert(seq.begin(), lm.start_symbol);
+  else if (seq.size() > N) seq.erase(seq.begin(), seq.end() - (N - 1));
+  else if (seq.size() == N) seq.resize(N - 1);                   // (sic) keeps the FIRST order-1 words
+  return lm_model_next(lm, seq.data(), seq.size());
+}
+
+uint32_t lm_next_count(const HostLM& lm, const LmNext& nx, uint32_t word) {
+  if (nx.status) return 0;
+  const LmLevel& lv = lm.level[nx.level];
+  const auto b = lv.word.begin();
+  const auto it = std::lower_bound(b + nx.from, b + nx.to, word);
+  return (it == b + nx.to || *it != word) ? 0u : lv.count[it - b];
+}
+
+double lm_next_score(const HostLM& lm, const LmNext& nx, uint32_t word) {   // scorerNext.ScoreNext
+  const uint32_t c = lm_next_count(lm, nx, word);
+  if (c == 0) return -100.0;
+  return std::log(1.0 * (double)c / (double)nx.context_count);
+}
+
+void lm_tokenize(const HostLM& lm, const uint8_t* text, size_t n, std::vector<std::string>& out) {
+  // strings.ToLower, strings.Trim(" "), then maximal runs of alphabet runes
+  std::vector<uint32_t> runes;
+  for (size_t i = 0; i < n;) {
+    size_t adv;
+    runes.push_back(host_lower_rune(host_next_rune(text + i, n - i, &adv)));
+    i += adv;
+  }
+  size_t a = 0, b = runes.size();
+  while (a < b && runes[a] == ' ') a++;
+  while (b > a && runes[b - 1] == ' ') b--;
+  out.clear();
+  std::string cur;
+  auto flush = [&] { if (!cur.empty()) { out.push_back(cur); cur.clear(); } };
+  for (size_t i = a; i < b; i++) {
+    const uint32_t r = runes[i];
+    if (!host_alphabet_has(lm.alphabet, r)) { flush(); continue; }
+    if (r < 0x80) cur.push_back((char)r);
+    else if (r < 0x800) { cur.push_back((char)(0xC0 | (r >> 6))); cur.push_back((char)(0x80 | (r & 0x3F))); }
+    else if (r < 0x10000) { cur.push_back((char)(0xE0 | (r >> 12))); cur.push_back((char)(0x80 | ((r >> 6) & 0x3F))); cur.push_back((char)(0x80 | (r & 0x3F))); }
+    else { cur.push_back((char)(0xF0 | (r >> 18))); cur.push_back((char)(0x80 | ((r >> 12) & 0x3F))); cur.push_back((char)(0x80 | ((r >> 6) & 0x3F))); cur.push_back((char)(0x80 | (r & 0x3F))); }
+  }
+  flush();
+}
+
+}  // namespace sg

@@ -79,6 +79,47 @@ int metric_max_y(int m, double alpha, int size);
 int metric_threshold(int m, double alpha, int a, int b);
 
 uint64_t mix64(uint64_t k);
+
+uint32_t host_next_rune(const uint8_t* s, size_t n, size_t* adv);   // Go range decoding (invalid byte -> U+FFFD, width 1)
+uint32_t host_lower_rune(uint32_t r);                                // unicode.ToLower (simple mappings)
+uint32_t host_utf8_width(uint32_t r);
+bool host_alphabet_has(const std::vector<std::string>& spec, uint32_t r);   // alphabet.CreateAlphabet(spec).Has(r)
+
+// ---- language model of the spellchecker caller (lm.cpp) ----
+constexpr uint32_t kUnknownWord = 0xFFFFFFFFu;      // pkg/lm/indexer.go:16
+constexpr uint32_t kNoContext = 0xFFFFFFFDu;        // InvalidContextOffset, pkg/lm/ngram_vector.go:25-27
+
+struct LmLevel {   // n-grams of one order, sorted by (parent, word); the index of an entry is its "context offset"
+  std::vector<uint32_t> word, count;
+  std::vector<uint32_t> child_begin;   // [n_parents + 2]: entries whose parent is p are child_begin[p] .. child_begin[p + 1];
+                                       // the last bucket (p = n_parents) holds entries without a parent (kNoContext)
+  uint64_t total = 0;                  // CorpusCount
+};
+
+struct HostLM {
+  std::vector<std::string> words;      // id order (lines of 1-gm)
+  std::unordered_map<std::string, uint32_t> id_of;
+  std::vector<LmLevel> level;          // order 1 .. N
+  uint32_t order = 0, start_symbol = kUnknownWord, end_symbol = kUnknownWord;
+  std::vector<std::string> alphabet;
+};
+
+struct LmNext {    // NGramModel.Next: the continuations of a context = one bucket of one level
+  int status = 0;  // 0 scorer, 1 nil scorer, 2 error (pkg/lm/ngram_model.go:64-98)
+  uint32_t level = 0, from = 0, to = 0;
+  uint32_t context_count = 0;          // count of the context itself (the denominator of ScoreNext)
+};
+
+int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const std::vector<std::string>& alphabet,
+                   HostLM& lm, std::string& err);
+uint32_t lm_word_id(const HostLM& lm, const std::string& token);
+double lm_model_score(const HostLM& lm, const uint32_t* ids, size_t n);
+double lm_score_word_ids(const HostLM& lm, const uint32_t* ids, size_t n);
+LmNext lm_model_next(const HostLM& lm, const uint32_t* ids, size_t n);
+LmNext lm_next(const HostLM& lm, const uint32_t* ids, size_t n);
+uint32_t lm_next_count(const HostLM& lm, const LmNext& nx, uint32_t word);
+double lm_next_score(const HostLM& lm, const LmNext& nx, uint32_t word);
+void lm_tokenize(const HostLM& lm, const uint8_t* text, size_t n, std::vector<std::string>& out);
 void set_error(const std::string& msg);
 
 }  // namespace sg
