@@ -11,6 +11,7 @@
 //   suggest::ResultItem         pkg/suggest/service.go:12-17
 //   suggest::metric::*          pkg/metric/{jaccard,cosine,dice,exact,overlap}.go (constructors only: the maths runs on the GPU)
 //   suggest::dictionary::*      pkg/dictionary/{dictionary,memory_dictionary,cdb_dictionary,helpers}.go
+//   suggest::lm::LanguageModel, suggest::spellchecker::SpellChecker   pkg/lm/language_model.go, pkg/spellchecker/spellchecker.go
 // Go `error` returns become exceptions (suggest::Error) carrying the reference's message.  The Go seam hides `k` in
 // a CollectorManagerFactory closure (collector.go:143-149); here it is an explicit argument, as in the C ABI, and
 // *Batch methods are additive (the GPU earns its keep on batches).
@@ -611,6 +612,86 @@ class Service {
   std::map<std::string, std::shared_ptr<dictionary::Dictionary>> dictionaries_;
   int device_;
 };
+
+// ---------------------------------------------------------------------------------------------
+// lm / spellchecker — pkg/lm/language_model.go, pkg/spellchecker/spellchecker.go
+// ---------------------------------------------------------------------------------------------
+namespace lm {
+using WordID = uint32_t;
+static const WordID UnknownWordID = 0xFFFFFFFFu;   // indexer.go:16
+static const double UnknownWordScore = -100.0;     // ngram_model.go:23
+
+struct Config {  // pkg/lm/config.go:13-23 (the fields the model and the tokenizer use)
+  std::string Name;
+  uint8_t NGramOrder = 3;
+  std::string OutputPath;                           // directory of the <k>-gm count files
+  std::vector<std::string> Alphabet;
+  std::string StartSymbol = "<S>", EndSymbol = "</S>";
+};
+
+class LanguageModel {  // language_model.go:8-14 over NewGoogleNGramReader(order, indexer, dir).Read (ngram_reader.go:38-98)
+ public:
+  explicit LanguageModel(const Config& c) {
+    std::vector<const char*> alpha;
+    for (auto& a : c.Alphabet) alpha.push_back(a.c_str());
+    NGramIndex::Check(sg_lm_load_google(c.OutputPath.c_str(), c.NGramOrder, c.StartSymbol.c_str(), c.EndSymbol.c_str(), alpha.data(),
+                                        (uint32_t)alpha.size(), &h_));
+  }
+  ~LanguageModel() { if (h_) sg_lm_release(h_); }
+  LanguageModel(const LanguageModel&) = delete;
+  LanguageModel& operator=(const LanguageModel&) = delete;
+  sg_lm* Handle() const { return h_; }
+
+  WordID GetWordID(const std::string& token) const { return sg_lm_word_id(h_, (const uint8_t*)token.data(), (uint32_t)token.size()); }
+  std::string Find(WordID id) const {                // Indexer.Find
+    char buf[512];
+    const int n = sg_lm_word(h_, id, buf, sizeof buf);
+    if (n < 0) return "<UNK>";
+    return std::string(buf, (size_t)std::min<int>(n, (int)sizeof buf));
+  }
+  double ScoreWordIDs(const std::vector<WordID>& ids) const { return sg_lm_score_word_ids(h_, ids.data(), (uint32_t)ids.size()); }
+  double ScoreSentence(const std::vector<std::string>& sentence) const {   // language_model.go:66-76
+    std::vector<WordID> ids;
+    for (auto& w : sentence) ids.push_back(GetWordID(w));
+    return ScoreWordIDs(ids);
+  }
+  size_t Size() const { return sg_lm_num_words(h_); }
+
+ private:
+  sg_lm* h_ = nullptr;
+};
+}  // namespace lm
+
+namespace spellchecker {
+class SpellChecker {  // spellchecker.go:14-37, wired like internal/spellchecker/dep/spellchecker.go:14-53
+ public:
+  SpellChecker(std::shared_ptr<lm::LanguageModel> model, const IndexDescription& indexDescription, int device = 0) : model_(std::move(model)) {
+    detail::DescC dc(indexDescription);
+    sg_index* h = nullptr;
+    NGramIndex::Check(sg_spell_index_build(model_->Handle(), &dc.d, device, &h));
+    index_ = std::make_shared<NGramIndex>(h);
+  }
+  // Predict — spellchecker.go:40-92
+  std::vector<std::string> Predict(const std::string& query, int topK, double similarity) const {
+    const uint64_t offs[2] = {0, query.size()};
+    std::vector<uint32_t> ids((size_t)topK + 1);
+    uint32_t count = 0;
+    NGramIndex::Check(sg_spell_predict_batch(index_->Handle(), model_->Handle(), (const uint8_t*)query.data(), offs, 1, (uint32_t)topK, similarity,
+                                             ids.data(), &count));
+    if (count == SG_COUNT_REF_PANIC) throw Error("reference behaviour: panic: makechan: size out of range");
+    if (count == SG_COUNT_REF_DEADLOCK) throw Error("reference behaviour: deadlock (unbuffered channel, suggester.go:62)");
+    if (count == SG_COUNT_LM_ERROR) throw Error("nGrams length should be less than the nGramModel order");   // ngram_model.go:66
+    if (count == SG_COUNT_TOO_LONG) throw Error("query has more than SG_MAX_QUERY_TERMS n-grams");
+    std::vector<std::string> out;
+    for (uint32_t i = 0; i < count; i++) out.push_back(model_->Find(ids[i]));
+    return out;
+  }
+
+ private:
+  std::shared_ptr<lm::LanguageModel> model_;
+  std::shared_ptr<NGramIndex> index_;
+};
+}  // namespace spellchecker
 
 }  // namespace suggest
 #endif  // SUGGEST_HIP_HPP

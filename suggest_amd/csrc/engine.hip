@@ -19,6 +19,8 @@
 #include <type_traits>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <functional>
 #include <string>
 
 #include "sg_internal.h"
@@ -1861,18 +1863,26 @@ int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, co
   // ---- host: last word + the continuations of its context ----
   std::vector<LmNext> next(n_q);
   std::vector<uint8_t> has_word(n_q, 0);
-  std::string words;
-  std::vector<uint64_t> w_offs(1, 0);
+  std::vector<std::string> last_word(n_q);
   std::vector<uint32_t> lm_from(n_q, 0), lm_to(n_q, 0);
-  std::vector<std::string> toks;
-  std::vector<uint32_t> ids;
-  for (uint32_t i = 0; i < n_q; i++) {
-    out_counts[i] = 0;
-    lm_tokenize(h, q_utf8 + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i]), toks);
-    next[i].status = 1;
-    if (!toks.empty()) {
+  auto parallel_for = [&](const std::function<void(uint32_t, uint32_t)>& body) {   // host steps are per query: spread them
+    const uint32_t n_thr = std::max(1u, std::min(std::min(std::thread::hardware_concurrency(), 32u), n_q / 2048u));
+    if (n_thr <= 1) { body(0, n_q); return; }
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_thr; t++)
+      pool.emplace_back(body, (uint32_t)((uint64_t)n_q * t / n_thr), (uint32_t)((uint64_t)n_q * (t + 1) / n_thr));
+    for (auto& th : pool) th.join();
+  };
+  parallel_for([&](uint32_t lo, uint32_t hi) {
+    std::vector<std::string> toks;
+    std::vector<uint32_t> ids;
+    for (uint32_t i = lo; i < hi; i++) {
+      out_counts[i] = 0;
+      lm_tokenize(h, q_utf8 + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i]), toks);
+      next[i].status = 1;
+      if (toks.empty()) continue;
       has_word[i] = 1;
-      words += toks.back();
+      last_word[i] = toks.back();
       ids.clear();
       for (size_t t = 0; t + 1 < toks.size(); t++) ids.push_back(lm_word_id(h, toks[t]));
       if (!ids.empty()) {                                       // spellchecker.go:94-107
@@ -1880,8 +1890,10 @@ int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, co
         if (next[i].status == 0) { lm_from[i] = lm->level_base[next[i].level] + next[i].from; lm_to[i] = lm->level_base[next[i].level] + next[i].to; }
       }
     }
-    w_offs.push_back(words.size());
-  }
+  });
+  std::string words;
+  std::vector<uint64_t> w_offs(1, 0);
+  for (uint32_t i = 0; i < n_q; i++) { words += last_word[i]; w_offs.push_back(words.size()); }
 
   // ---- GPU: LM-ranked autocomplete of every last word ----
   HIP_TRY(hipSetDevice(index->device));
@@ -1938,25 +1950,27 @@ int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, co
   // ---- host: merge, re-rank, truncate ----
   std::vector<uint32_t> fuzzy_of(n_q, 0xFFFFFFFFu);
   for (size_t j = 0; j < need.size(); j++) fuzzy_of[need[j]] = (uint32_t)j;
-  std::vector<uint32_t> cands;
-  for (uint32_t i = 0; i < n_q; i++) {
-    if (out_counts[i] == SG_COUNT_TOO_LONG || !has_word[i]) continue;
-    if (next[i].status == 2) { out_counts[i] = SG_COUNT_LM_ERROR; continue; }
-    cands.assign(a_ids.begin() + (size_t)i * top_k, a_ids.begin() + (size_t)i * top_k + a_cnt[i]);
-    if (fuzzy_of[i] != 0xFFFFFFFFu) {
-      const uint32_t j = fuzzy_of[i], c = f_cnt[j];
-      if (c >= SG_COUNT_TOO_LONG) { out_counts[i] = c; continue; }       // the reference panics / dead-locks here (suggester.go:62)
-      for (uint32_t x = 0; x < c; x++) {                                   // merge — spellchecker.go:133-150
-        const uint32_t y = f_ids[(size_t)j * top_k + x];
-        if (std::find(cands.begin(), cands.end(), y) == cands.end()) cands.push_back(y);
+  parallel_for([&](uint32_t lo, uint32_t hi) {
+    std::vector<uint32_t> cands;
+    for (uint32_t i = lo; i < hi; i++) {
+      if (out_counts[i] == SG_COUNT_TOO_LONG || !has_word[i]) continue;
+      if (next[i].status == 2) { out_counts[i] = SG_COUNT_LM_ERROR; continue; }
+      cands.assign(a_ids.begin() + (size_t)i * top_k, a_ids.begin() + (size_t)i * top_k + a_cnt[i]);
+      if (fuzzy_of[i] != 0xFFFFFFFFu) {
+        const uint32_t j = fuzzy_of[i], c = f_cnt[j];
+        if (c >= SG_COUNT_TOO_LONG) { out_counts[i] = c; continue; }     // the reference panics / dead-locks here (suggester.go:62)
+        for (uint32_t x = 0; x < c; x++) {                                 // merge — spellchecker.go:133-150
+          const uint32_t y = f_ids[(size_t)j * top_k + x];
+          if (std::find(cands.begin(), cands.end(), y) == cands.end()) cands.push_back(y);
+        }
       }
+      if (next[i].status == 0)                                             // sort.SliceStable by ScoreNext desc (monotone in the count)
+        std::stable_sort(cands.begin(), cands.end(), [&](uint32_t x, uint32_t y) { return lm_next_count(h, next[i], x) > lm_next_count(h, next[i], y); });
+      if (top_k < cands.size()) cands.resize(row);                         // candidates[:topK+1] (sic)
+      out_counts[i] = (uint32_t)cands.size();
+      std::copy(cands.begin(), cands.end(), out_ids + (size_t)i * row);
     }
-    if (next[i].status == 0)                                               // sort.SliceStable by ScoreNext desc (monotone in the count)
-      std::stable_sort(cands.begin(), cands.end(), [&](uint32_t x, uint32_t y) { return lm_next_count(h, next[i], x) > lm_next_count(h, next[i], y); });
-    if (top_k < cands.size()) cands.resize(row);                           // candidates[:topK+1] (sic)
-    out_counts[i] = (uint32_t)cands.size();
-    std::copy(cands.begin(), cands.end(), out_ids + (size_t)i * row);
-  }
+  });
   return SG_OK;
 }
 

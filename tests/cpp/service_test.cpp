@@ -201,6 +201,31 @@ static void TestDevice(const std::string& golden) {
   }
 }
 
+// ---- language model + spellchecker ---------------------------------------------------------------------------------
+static void TestSpell(const std::string& golden, bool device) {
+  const Json ref = Json::Parse(dictionary::ReadFile(golden + "/reference_tests.json", "golden"));
+  const Json& g = ref.at("lm");
+  lm::Config config;
+  config.NGramOrder = (uint8_t)g.at("order").num;
+  config.OutputPath = golden + "/lm";
+  config.Alphabet = {"english", "russian", "numbers", "-."};
+  config.StartSymbol = g.at("startSymbol").str;
+  config.EndSymbol = g.at("endSymbol").str;
+  auto model = std::make_shared<lm::LanguageModel>(config);
+  for (const Json& c : g.at("score_sentence").arr)              // language_model_test.go:52-70
+    EXPECT(std::fabs(model->ScoreSentence(Strings(c.at(0))) - c.at(1).num) < g.at("tolerance").num, "ScoreSentence");
+  EXPECT(model->GetWordID("sam") == 1 && model->GetWordID("nope") == lm::UnknownWordID && model->Find(1) == "sam", "indexer");
+  if (!device) return;
+  IndexDescription d;                                            // cmd/spellchecker/cmd/eval.go:16-23
+  d.Name = "words"; d.NGramSize = 3; d.Wrap[0] = "^"; d.Wrap[1] = "$"; d.Pad = "$";
+  d.Alphabet = {"english", "russian", "numbers", "$^'"};
+  spellchecker::SpellChecker checker(model, d);
+  EXPECT(checker.Predict("i am sa", 5, 0.3) == std::vector<std::string>{"sam"}, "Predict completes the word");
+  EXPECT((checker.Predict("<s> i am", 5, 0.3) == std::vector<std::string>{"am", "sam", "ham"}), "Predict tops up with the fuzzy search");
+  EXPECT(checker.Predict("gren egs", 5, 0.3) == std::vector<std::string>{"eggs"}, "Predict corrects a typo");
+  EXPECT(checker.Predict("", 5, 0.3).empty(), "empty query");
+}
+
 int main(int argc, char** argv) {
   bool cpu_only = false;
   std::string golden;
@@ -214,6 +239,7 @@ int main(int argc, char** argv) {
   }
   try {
     TestHost(golden);
+    TestSpell(golden, !cpu_only);
     if (!cpu_only) TestDevice(golden);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAIL uncaught: %s\n", e.what());

@@ -262,9 +262,12 @@ class OracleLM:
             raise IOError(err.value.decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().or_lm_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().or_lm_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def words(self):
         L = lib()
