@@ -39,8 +39,9 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--dict-variant", default="uniform", choices=["uniform", "skewed", "families", "skewed-families"],
                     help="SURVEY.md §8d dictionary variants (headline = uniform); families = base + 3 edited copies")
-    ap.add_argument("--build", default="device", choices=["device", "host"],
-                    help="index build: on the GPU (sg_index_build_device) or on the host (sg_index_build); same arrays")
+    ap.add_argument("--build", default="host", choices=["device", "host"],
+                    help="index build: on the host (sg_index_build, ~6 s at 10M) or on the GPU (sg_index_build_device, 0.4 s); same "
+                         "arrays — but the store uploaded after a device build lands 2 %% slower for the search kernel (placement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
     ap.add_argument("--gather", action="store_true",

@@ -666,7 +666,10 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 // ------------------------------------------------------------------------------------------
 // kParts = false: one workgroup per query (the batch launch).  kParts = true: the second launch, a few thousand
 // persistent wavefronts that take the queued parts of split queries off the item queue until it is empty.
-template <bool kParts>
+// kLM = true: the spellchecker's autocomplete (candidates ranked by the language model) — its own instantiation, so the
+// search kernel proper carries none of its registers (with the LM code inlined the shared kernel spilled 750 bytes per
+// lane and the headline batch went from 2.6 to 4.4 ms).
+template <bool kParts, bool kLM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
   do {   // one query (or one part of one): `break` leaves it
   const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
-  const uint32_t lm_from = a.lm_values ? a.lm_from[qi] : 0u, lm_to = a.lm_values ? a.lm_to[qi] : 0u;
+  const uint32_t lm_from = kLM ? a.lm_from[qi] : 0u, lm_to = kLM ? a.lm_to[qi] : 0u;
   uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     //      verified together (their binary searches overlap in flight) instead of stalling the stream ----
     uint32_t qn = 0;
     auto offer = [&](uint32_t d, int overlap, int w) {
-      if (a.autocomplete && a.lm_values)                                    // lmCollector: score = ScoreNext(doc), monotone in the count
+      if (kLM)                                                              // lmCollector: score = ScoreNext(doc), monotone in the count
         topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
       else if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);     // score = -docID, collector.go:104-106
       else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
@@ -1344,8 +1347,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
 
-#define sg_search_kernel sg_search_kernel_t<false>
-#define sg_parts_kernel sg_search_kernel_t<true>
+#define sg_search_kernel sg_search_kernel_t<false, false>
+#define sg_parts_kernel sg_search_kernel_t<true, false>
+#define sg_lm_kernel sg_search_kernel_t<false, true>
 
 // ------------------------------------------------------------------------------------------
 // host side: handle, upload, launches, C ABI
@@ -1491,7 +1495,7 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
     HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
     a.scratch_s = (uint64_t*)scratch;
     a.scratch_id = (uint32_t*)((char*)scratch + (size_t)n_q * k * 8);
-  } else if (index->split_chunks) {
+  } else if (index->split_chunks && !lm) {
     // Splitting pays (1) when the batch cannot fill the machine by itself: every query above 2 MiB of postings is cut
     // into 1 MiB parts; (2) for the outliers of a big batch, which would otherwise be its tail: one wavefront streams
     // ~1/3000 of the machine's rate, so a query holding more than 2x the expected volume and more than ~1/30000 of the
@@ -1521,7 +1525,8 @@ int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, i
     a.part_s = (uint64_t*)(base + o_ps);
     a.part_id = (uint32_t*)(base + o_pid);
   }
-  hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
+  if (lm) hipLaunchKernelGGL(sg_lm_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
+  else hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
   HIP_TRY(hipGetLastError());
   if (a.split_ctl) {     // the queued parts of split queries: persistent wavefronts, which leave at once if there are none
     hipLaunchKernelGGL(sg_parts_kernel, dim3(index->parts_grid), dim3(64), lds_bytes(a.log2_cnt), stream, a);
@@ -1676,6 +1681,7 @@ int sg_index_upload(sg_index* ix, int device) {
   env = getenv("SG_FILTER_LEVEL");            // tuning knob: 0..3 = chance of a false bucket 3e-5 .. 1e-6 (default 2)
   if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->filter_level = (uint32_t)v; }
   HIP_TRY(hipFuncSetAttribute((const void*)sg_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(ix->log2_cnt)));
+  HIP_TRY(hipFuncSetAttribute((const void*)sg_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(ix->log2_cnt)));
   {  // per-launch scratch comes from the device's stream-ordered pool: keep freed blocks instead of returning them
     hipMemPool_t pool;
     uint64_t keep = ~0ull;
