@@ -1953,12 +1953,13 @@ int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, co
 
   // ---- GPU: LM-ranked autocomplete of every last word ----
   HIP_TRY(hipSetDevice(index->device));
-  hipStream_t st;
-  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  HostCtx* ctx;
+  if ((rc = host_ctx(index->device, 0, &ctx))) return rc;
+  hipStream_t st = ctx->stream;
   std::vector<void*> dev;
-  auto cleanup = [&]() { for (void* p : dev) (void)hipFree(p); (void)hipStreamDestroy(st); };
+  auto cleanup = [&]() { for (void* p : dev) (void)hipFreeAsync(p, st); (void)hipStreamSynchronize(st); };
 #define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return SG_E_HIP; } } while (0)
-  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e == hipSuccess) dev.push_back(*p); return e; };
+  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMallocAsync(p, std::max<size_t>(bytes, 16), st); if (e == hipSuccess) dev.push_back(*p); return e; };
   void *dq, *doffs, *dfrom, *dto, *dids, *dcnt;
   TRY3(dalloc(&dq, words.size())); TRY3(dalloc(&doffs, (size_t)(n_q + 1) * 8)); TRY3(dalloc(&dfrom, (size_t)n_q * 4));
   TRY3(dalloc(&dto, (size_t)n_q * 4)); TRY3(dalloc(&dids, (size_t)n_q * top_k * 4)); TRY3(dalloc(&dcnt, (size_t)n_q * 4));

@@ -23,3 +23,14 @@ qb, qo = synth.make_queries(4096, blob, offs, seed=2)
 ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
 for n in (1, 16, 256, 4096):
     print("1M dict, %4d queries per call: %8.1f us per call" % (n, run(ix, qb, qo, n)))
+
+# SpellChecker.Predict per call (reference fixture model)
+from suggest_amd import LanguageModel, SpellChecker
+lm = LanguageModel(os.path.join(ROOT, "tests", "golden", "lm"), 3)
+sc = SpellChecker(lm)
+for _ in range(10):
+    sc.Predict("i am sa", 5, 0.3)
+t0 = time.perf_counter()
+for _ in range(200):
+    sc.Predict("i am sa", 5, 0.3)
+print("SpellChecker.Predict, one query per call: %.1f us" % ((time.perf_counter() - t0) / 200 * 1e6))
