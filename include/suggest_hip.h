@@ -118,6 +118,13 @@ typedef struct sg_lm sg_lm;
  * of 1-gm; `alphabet` is the words alphabet of the lm config (pkg/lm/config.go:25-27) used by the query tokenizer. */
 int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol,
                       const char* const* alphabet, uint32_t n_alphabet, sg_lm** out);
+/* NGramBuilder.Build over NewSentenceRetriever + googleNGramFormatWriter.Write (pkg/lm/ngram_builder.go:16-64,
+ * sentence_retriever.go:17-81, ngram_writer.go:32-76) — what `lm build-lm` does to a corpus: sentences are cut at the
+ * runes of `separators`, tokenised, wrapped in start/end symbols and their k-grams (k = 1..order) counted into
+ * <out_dir>/<k>-gm.  Lines come in order of first appearance (the reference's order is Go-map random). */
+int sg_lm_build_google(const uint8_t* text, uint64_t len, uint32_t order, const char* start_symbol, const char* end_symbol,
+                       const char* const* alphabet, uint32_t n_alphabet, const char* const* separators, uint32_t n_separators,
+                       const char* out_dir);
 void sg_lm_retain(sg_lm* lm);
 void sg_lm_release(sg_lm* lm);
 uint32_t sg_lm_num_words(const sg_lm* lm);

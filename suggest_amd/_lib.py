@@ -20,7 +20,7 @@ EXPORTS = [
     "sg_index_build", "sg_index_build_device", "sg_index_digest", "sg_index_load_reference", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
     "sg_autocomplete_batch_device", "sg_index_retain", "sg_index_release", "sg_last_error", "sg_index_stats",
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
-    "sg_lm_load_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
+    "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
@@ -64,6 +64,7 @@ def lib():
     L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    L.sg_lm_build_google.argtypes = [C.c_char_p, u64, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p]
     L.sg_lm_retain.argtypes = [vp]
     L.sg_lm_retain.restype = None
     L.sg_lm_release.argtypes = [vp]

@@ -1836,6 +1836,19 @@ int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol,
   return SG_OK;
 }
 
+int sg_lm_build_google(const uint8_t* text, uint64_t len, uint32_t order, const char* start_symbol, const char* end_symbol,
+                       const char* const* alphabet, uint32_t n_alphabet, const char* const* separators, uint32_t n_separators,
+                       const char* out_dir) {
+  if ((!text && len) || !start_symbol || !end_symbol || !out_dir) { set_error("null argument"); return SG_E_INVALID; }
+  std::vector<std::string> alpha, seps;
+  for (uint32_t i = 0; i < n_alphabet; i++) alpha.emplace_back(alphabet[i]);
+  for (uint32_t i = 0; i < n_separators; i++) seps.emplace_back(separators[i]);
+  std::string err;
+  const int rc = lm_build_google_files(text, (size_t)len, order, start_symbol, end_symbol, alpha, seps, out_dir, err);
+  if (rc) set_error(err);
+  return rc;
+}
+
 void sg_lm_retain(sg_lm* lm) { if (lm) lm->refs.fetch_add(1); }
 void sg_lm_release(sg_lm* lm) {
   if (!lm || lm->refs.fetch_sub(1) != 1) return;

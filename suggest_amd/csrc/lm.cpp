@@ -174,6 +174,57 @@ double lm_next_score(const HostLM& lm, const LmNext& nx, uint32_t word) {   // s
   return std::log(1.0 * (double)c / (double)nx.context_count);
 }
 
+// NGramBuilder.Build + googleNGramFormatWriter.Write (pkg/lm/ngram_builder.go:16-64, ngram_writer.go:32-76) over
+// NewSentenceRetriever (sentence_retriever.go:17-81): the text is cut into sentences at the runes of `separators`,
+// every sentence is tokenised (lm tokenizer), wrapped in start/end symbols and all its k-grams, k = 1..order, are
+// counted; <dir>/<k>-gm gets one "w1 .. wk\tcount" line per distinct k-gram.  The reference walks a trie of Go maps
+// (random line order); here lines come in order of first appearance, so word ids (lines of 1-gm) are deterministic.
+int lm_build_google_files(const uint8_t* text, size_t n, uint32_t order, const char* start_symbol, const char* end_symbol,
+                          const std::vector<std::string>& alphabet, const std::vector<std::string>& separators, const char* out_dir,
+                          std::string& err) {
+  if (order < 1 || order > 8) { err = "nGramOrder should be >= 1"; return SG_E_INVALID; }
+  HostLM tok;                                                  // only its alphabet is used (by lm_tokenize)
+  tok.alphabet = alphabet;
+  std::vector<std::map<std::vector<std::string>, std::pair<uint64_t, uint64_t>>> counts(order);   // gram -> (first seen, count)
+  uint64_t clock = 0;
+  std::vector<std::string> words, sentence;
+  auto flush = [&](size_t from, size_t to) {
+    if (to <= from) return;
+    lm_tokenize(tok, text + from, to - from, words);
+    if (words.empty()) return;                                 // ngram_builder.go:51-53
+    sentence.clear();
+    sentence.push_back(start_symbol);
+    sentence.insert(sentence.end(), words.begin(), words.end());
+    sentence.push_back(end_symbol);
+    for (uint32_t k = 1; k <= order; k++)
+      for (size_t i = 0; i + k <= sentence.size(); i++) {
+        auto& slot = counts[k - 1][std::vector<std::string>(sentence.begin() + i, sentence.begin() + i + k)];
+        if (slot.second++ == 0) slot.first = clock++;
+      }
+  };
+  size_t start = 0;
+  for (size_t i = 0; i < n;) {
+    size_t adv;
+    const uint32_t r = host_next_rune(text + i, n - i, &adv);
+    if (host_alphabet_has(separators, r)) { flush(start, i); start = i + adv; }
+    i += adv;
+  }
+  flush(start, n);
+  for (uint32_t k = 1; k <= order; k++) {
+    std::vector<std::pair<uint64_t, const std::vector<std::string>*>> lines;
+    for (const auto& kv : counts[k - 1]) lines.emplace_back(kv.second.first, &kv.first);
+    std::sort(lines.begin(), lines.end());
+    std::ofstream f(std::string(out_dir) + "/" + std::to_string(k) + "-gm", std::ios::binary);
+    if (!f) { err = "failed to create an output: " + std::string(out_dir) + "/" + std::to_string(k) + "-gm"; return SG_E_INVALID; }
+    for (const auto& ln : lines) {
+      const auto& gram = *ln.second;
+      for (size_t i = 0; i < gram.size(); i++) { if (i) f << ' '; f << gram[i]; }
+      f << '\t' << counts[k - 1][gram].second << '\n';
+    }
+  }
+  return SG_OK;
+}
+
 void lm_tokenize(const HostLM& lm, const uint8_t* text, size_t n, std::vector<std::string>& out) {
   // strings.ToLower, strings.Trim(" "), then maximal runs of alphabet runes
   std::vector<uint32_t> runes;

@@ -112,6 +112,9 @@ struct LmNext {    // NGramModel.Next: the continuations of a context = one buck
 
 int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const std::vector<std::string>& alphabet,
                    HostLM& lm, std::string& err);
+int lm_build_google_files(const uint8_t* text, size_t n, uint32_t order, const char* start_symbol, const char* end_symbol,
+                          const std::vector<std::string>& alphabet, const std::vector<std::string>& separators, const char* out_dir,
+                          std::string& err);
 uint32_t lm_word_id(const HostLM& lm, const std::string& token);
 double lm_model_score(const HostLM& lm, const uint32_t* ids, size_t n);
 double lm_score_word_ids(const HostLM& lm, const uint32_t* ids, size_t n);

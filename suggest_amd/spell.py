@@ -26,6 +26,16 @@ class LanguageModel:
         self._h = h
         self.order = int(order)
 
+    @staticmethod
+    def build_files(text, directory, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-."),
+                    separators=("\n",)):
+        """`lm build-lm`: count the k-grams of a corpus into <directory>/{1..order}-gm (pkg/lm/ngram_builder.go, ngram_writer.go)"""
+        raw = _enc(text)
+        alpha = (C.c_char_p * len(alphabet))(*[_enc(a) for a in alphabet])
+        seps = (C.c_char_p * len(separators))(*[_enc(a) for a in separators])
+        _lib.check(_lib.lib().sg_lm_build_google(raw, len(raw), int(order), _enc(start_symbol), _enc(end_symbol), alpha, len(alphabet),
+                                                 seps, len(separators), _enc(directory)))
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().sg_lm_release(self._h)

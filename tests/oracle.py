@@ -57,6 +57,7 @@ def lib():
         L.or_lm_load.restype = C.c_void_p
         L.or_lm_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.or_lm_free.argtypes = [C.c_void_p]
+        L.or_lm_build_google.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.or_lm_words.restype = C.c_uint32
         L.or_lm_words.argtypes = [C.c_void_p]
         L.or_lm_word.restype = C.c_char_p
@@ -249,6 +250,16 @@ def metric_threshold(m, a, sa, sb):
 
 def metric_score(m, inter, sa, sb):
     return lib().or_metric_score(METRICS[m], inter, sa, sb)
+
+
+def lm_build_files(text, directory, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-."),
+                   separators=("\n",)):
+    """or_lm_build_google: corpus -> <directory>/{1..order}-gm (NGramBuilder + googleNGramFormatWriter)"""
+    raw = _b(text)
+    rc = lib().or_lm_build_google(raw, len(raw), int(order), _b(start_symbol), _b(end_symbol), b"\n".join(_b(a) for a in alphabet),
+                                  b"\x1f".join(_b(a) for a in separators), _b(directory))
+    if rc:
+        raise IOError("cannot write n-gram files to %s" % directory)
 
 
 class OracleLM:

@@ -147,3 +147,45 @@ def test_predict_synthetic_language_model(tmp_path):
         queries.append((" ".join(ctx + [word])).encode())
     for top_k, sim in ((5, 0.5), (20, 0.4), (1, 0.7)):
         _assert_same_predictions(sc, ora_lm, ora_ix, queries, top_k, sim)
+
+
+def _gram_files(directory, order=3):
+    out = []
+    for k in range(1, order + 1):
+        with open(os.path.join(directory, "%d-gm" % k), "rb") as f:
+            out.append(sorted(f.read().splitlines()))
+    return out
+
+
+def test_lm_builder_reproduces_the_reference_fixture(g, tmp_path):
+    """`lm build-lm` (NGramBuilder + SentenceRetriever + googleNGramFormatWriter): the reference's fixture files are what
+    its builder wrote for testdata/test.txt — product and oracle builders must write the same lines (as multisets)."""
+    from suggest_amd import LanguageModel
+    b = g["build"]
+    want = _gram_files(LM_DIR)
+    prod, ora = tmp_path / "prod", tmp_path / "ora"
+    prod.mkdir(); ora.mkdir()
+    LanguageModel.build_files(b["text"], str(prod), g["order"], g["startSymbol"], g["endSymbol"], b["alphabet"], b["separators"])
+    oracle.lm_build_files(b["text"], str(ora), g["order"], g["startSymbol"], g["endSymbol"], b["alphabet"], b["separators"])
+    assert _gram_files(str(prod)) == want
+    assert _gram_files(str(ora)) == want
+    lm = LanguageModel(str(prod), g["order"], g["startSymbol"], g["endSymbol"])
+    for words, expected in g["score_sentence"]:
+        assert abs(lm.ScoreSentence(words) - expected) < g["tolerance"]
+
+
+def test_lm_builder_matches_oracle_on_messy_text(tmp_path):
+    from suggest_amd import LanguageModel
+    rnd = np.random.RandomState(11)
+    vocab = ["alpha", "beta", "Gamma", "дельта", "ЭПСИЛОН", "x-ray", "e.g", "42", "naïve", "don't"]
+    text = ""
+    for _ in range(400):
+        text += " ".join(vocab[int(i)] for i in rnd.randint(0, len(vocab), size=int(rnd.randint(0, 9))))
+        text += ["\n", ".", "!", " ?", "\n\n", " ", ";"][int(rnd.randint(0, 7))]
+    text = text.encode() + b"\xff tail \xc3\n"
+    for seps, alpha in (((".", "?", "!", "\n"), ("english", "russian", "numbers", "-'")), (("\n",), ("english", "numbers"))):
+        prod, ora = tmp_path / ("p%d" % len(seps)), tmp_path / ("o%d" % len(seps))
+        prod.mkdir(); ora.mkdir()
+        LanguageModel.build_files(text, str(prod), 4, "<S>", "</S>", alpha, seps)
+        oracle.lm_build_files(text, str(ora), 4, "<S>", "</S>", alpha, seps)
+        assert _gram_files(str(prod), 4) == _gram_files(str(ora), 4)
