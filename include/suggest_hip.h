@@ -71,6 +71,12 @@ int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, c
 int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device,
                           sg_index** out);
 
+/* Either builder (device < 0: host) with at least `min_segments` cardinality segments: the shards of a dictionary split by
+ * docID range (suggest_amd/distributed.py) agree on the global number, so that every shard clips the
+ * window [MinY, MaxY] at the same segment (suggester.go:57-59) as the unsharded index would. */
+int sg_index_build_ex(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments,
+                      int device, sg_index** out);
+
 /* NewFSBuilder + Reader.Read (pkg/suggest/ngram_index_builder.go:44-83, pkg/index/index_reader.go:29-120): loads an
  * index the reference itself built — <name>.hd (gob header) and <name>.dl (VB / skip-VB / roaring posting lists,
  * pkg/index/codec.go:39-51) — into the same CSR.  `desc` must be the IndexDescription the files were built with. */

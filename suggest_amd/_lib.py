@@ -17,7 +17,7 @@ SG_MAX_QUERY_TERMS = 128
 SG_MAX_TOPK = 1024
 
 EXPORTS = [
-    "sg_index_build", "sg_index_build_device", "sg_index_digest", "sg_index_load_reference", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
+    "sg_index_build", "sg_index_build_device", "sg_index_build_ex", "sg_index_digest", "sg_index_load_reference", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
     "sg_autocomplete_batch_device", "sg_index_retain", "sg_index_release", "sg_last_error", "sg_index_stats",
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
@@ -56,6 +56,7 @@ def lib():
     vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
     L.sg_index_build.argtypes = [vp, vp, u32, C.POINTER(SgDesc), C.POINTER(vp)]
     L.sg_index_build_device.argtypes = [vp, vp, u32, C.POINTER(SgDesc), i32, C.POINTER(vp)]
+    L.sg_index_build_ex.argtypes = [vp, vp, u32, C.POINTER(SgDesc), u32, i32, C.POINTER(vp)]
     L.sg_index_digest.argtypes = [vp, vp]
     L.sg_index_load_reference.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SgDesc), C.POINTER(vp)]
     L.sg_index_upload.argtypes = [vp, i32]

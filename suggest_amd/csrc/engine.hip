@@ -1544,42 +1544,49 @@ extern "C" {
 
 const char* sg_last_error(void) { return g_err.c_str(); }
 
-int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out) {
+static int build_any(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments, int device,
+                     sg_index** out) {
   if (!out || (!utf8 && n_docs) || !offs) { set_error("null argument"); return SG_E_INVALID; }
   auto* ix = new (std::nothrow) sg_index();
   if (!ix) return SG_E_NOMEM;
+  ix->host.min_segments = min_segments;
   std::string err;
   int rc;
   try {
-    rc = build_host_index(utf8, offs, n_docs, desc, ix->host, err);
-  } catch (const std::bad_alloc&) { rc = SG_E_NOMEM; err = "out of host memory"; }
-  if (rc) { set_error(err); delete ix; return rc; }
-  if (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX) {
-    set_error("wrap strings longer than 8 runes"); delete ix; return SG_E_UNSUPPORTED;
+    if (device < 0) {
+      rc = build_host_index(utf8, offs, n_docs, desc, ix->host, err);
+      if (rc) set_error(err);
+    } else {
+      rc = init_description(desc, ix->host, err);
+      if (rc) set_error(err);
+      else rc = build_on_device(ix, utf8, offs, n_docs, device);
+    }
+  } catch (const std::bad_alloc&) {
+    set_error("out of host memory"); rc = SG_E_NOMEM;
   }
+  for (void* p : ix->allocs) (void)hipFree(p);   // the description tables of a device build; sg_index_upload makes its own
+  ix->allocs.clear();
+  ix->device_bytes = 0;
+  if (!rc && (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX)) {
+    set_error("wrap strings longer than 8 runes"); rc = SG_E_UNSUPPORTED;
+  }
+  if (rc) { delete ix; return rc; }
   *out = ix;
   return SG_OK;
 }
 
+int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out) {
+  return build_any(utf8, offs, n_docs, desc, 0, -1, out);
+}
+
 int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device, sg_index** out) {
-  if (!out || (!utf8 && n_docs) || !offs) { set_error("null argument"); return SG_E_INVALID; }
-  auto* ix = new (std::nothrow) sg_index();
-  if (!ix) return SG_E_NOMEM;
-  std::string err;
-  int rc;
-  try {
-    rc = init_description(desc, ix->host, err);
-    if (rc) set_error(err);
-    else rc = build_on_device(ix, utf8, offs, n_docs, device);
-  } catch (const std::bad_alloc&) {
-    set_error("out of host memory"); rc = SG_E_NOMEM;
-  }
-  for (void* p : ix->allocs) (void)hipFree(p);   // the description tables of the build; sg_index_upload makes its own
-  ix->allocs.clear();
-  ix->device_bytes = 0;
-  if (rc) { delete ix; return rc; }
-  *out = ix;
-  return SG_OK;
+  if (device < 0) { set_error("bad device"); return SG_E_INVALID; }
+  return build_any(utf8, offs, n_docs, desc, 0, device, out);
+}
+
+int sg_index_build_ex(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments, int device,
+                      sg_index** out) {
+  return build_any(utf8, offs, n_docs, desc, min_segments, device, out);
 }
 
 int sg_index_digest(const sg_index* ix, uint64_t out[4]) {

@@ -329,7 +329,7 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
     doc_off[d + 1] = doc_terms.size();
   }
   // indexer_writer.go:69-73: len(indices) = max cardinality + 1
-  const uint32_t S = n_docs ? max_card + 1 : 0;
+  const uint32_t S = n_docs ? std::max(max_card + 1, ix.min_segments) : 0;
   ix.n_segments = S;
   const size_t nT = ix.term_key.size();
   ix.n_postings = doc_terms.size();

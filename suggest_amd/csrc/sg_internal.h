@@ -48,6 +48,7 @@ struct HostIndex {
 
   uint64_t n_docs = 0;
   uint32_t n_segments = 0;  // == header.Indices of the reference (max cardinality + 1)
+  uint32_t min_segments = 0;  // builders: at least this many segments (docID-sharded indexes agree on the global number)
   std::vector<uint64_t> term_key;                    // termID -> key
   std::unordered_map<uint64_t, uint32_t> term_of;    // key -> termID
   std::vector<uint32_t> seg_off;                     // [n_terms*(S+1)] chunk (16 B) offsets, term-major

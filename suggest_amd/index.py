@@ -47,7 +47,7 @@ def _c_desc(d):
 
 
 class NGramIndex:
-    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None, build="host"):
+    def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None, build="host", min_segments=0):
         """build="host": sg_index_build (CPU tokenise + CSR); build="device": sg_index_build_device (same arrays, built on the
         GPU `device`; documents with more than 128 n-grams are not supported there)."""
         L = _lib.lib()
@@ -65,13 +65,10 @@ class NGramIndex:
             self.n_docs = len(offs) - 1
             desc = _c_desc(d)
             h = C.c_void_p()
-            if build == "device":
-                _lib.check(L.sg_index_build_device(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc),
-                                                   int(device), C.byref(h)))
-            elif build == "host":
-                _lib.check(L.sg_index_build(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc), C.byref(h)))
-            else:
+            if build not in ("host", "device"):
                 raise ValueError("build must be 'host' or 'device'")
+            _lib.check(L.sg_index_build_ex(blob.ctypes.data if blob.size else None, offs.ctypes.data, self.n_docs, C.byref(desc),
+                                           int(min_segments), int(device) if build == "device" else -1, C.byref(h)))
             self._h = h
         if upload:
             self.upload(device)

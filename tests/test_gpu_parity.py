@@ -412,3 +412,32 @@ def test_device_index_build_rejects_documents_beyond_the_tokeniser():
     with pytest.raises(Exception, match="sg_index_build"):
         NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False, build="device")
     NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False)      # the host builder takes it
+
+
+def test_doc_sharded_index_merges_to_the_unsharded_result():
+    """SURVEY.md §8e alternative design on one GPU: three docID-range shards (uneven: the last shard has shorter
+    documents, so it has to be rebuilt with the global number of segments) searched separately and merged."""
+    import torch
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    from suggest_amd.distributed import merge_topk, shard_bounds
+    desc = IndexDescription(**synth.DESCRIPTION)
+    blob, offs = synth.make_dict(90000, seed=71, families=3)
+    docs = synth.unpack(blob, offs)
+    docs[60000:] = [d[:10] for d in docs[60000:]]                    # the last shard only has short documents
+    blob, offs = oracle.pack_strings(docs)
+    qb, qo = synth.make_queries(512, blob, offs, seed=72)
+    full = NGramIndex(blob=blob, offs=offs, description=desc)
+    S = full.stats()["n_segments"]
+    k = 10
+    rows = []
+    for r in range(3):
+        lo, hi = shard_bounds(len(docs), 3, r)
+        sb, so = blob[int(offs[lo]):int(offs[hi])], (offs[lo:hi + 1] - offs[lo]).astype(np.uint64)
+        shard = NGramIndex(blob=sb, offs=so, description=desc, min_segments=S, build="device" if r == 1 else "host")
+        assert shard.stats()["n_segments"] == S
+        ids, sc, cnt = shard.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.4, k=k)
+        rows.append((torch.from_numpy(ids.astype(np.int64) + lo), torch.from_numpy(sc), torch.from_numpy(cnt.astype(np.int64))))
+    m_ids, m_sc, m_cnt = merge_topk(torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows]), torch.stack([r[2] for r in rows]), k)
+    merged = (m_ids.numpy().astype(np.uint32), m_sc.numpy(), m_cnt.numpy().astype(np.uint32))
+    assert_same(merged, full.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.4, k=k))
+    assert (merged[2] > 1).mean() > 0.3
