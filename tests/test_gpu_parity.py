@@ -441,3 +441,36 @@ def test_doc_sharded_index_merges_to_the_unsharded_result():
     merged = (m_ids.numpy().astype(np.uint32), m_sc.numpy(), m_cnt.numpy().astype(np.uint32))
     assert_same(merged, full.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.4, k=k))
     assert (merged[2] > 1).mean() > 0.3
+
+
+def test_limits_long_ngrams_max_k_and_query_length():
+    """The edges of the device path: n-grams of 5 and 8 runes (the 64-bit term key is full at 8), k = SG_MAX_TOPK,
+    queries with exactly SG_MAX_QUERY_TERMS n-grams (answered) and one more (flagged, never answered wrongly)."""
+    import random
+    from suggest_amd import NGramIndex, IndexDescription, _lib
+    rng = random.Random(77)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(4, 24))) for _ in range(3000)]
+    for q in (5, 8):
+        desc = dict(ngram_size=q, wrap=("$", "$"), pad="$", alphabet=("english", "$"))
+        gpu = NGramIndex(words, IndexDescription(**desc))
+        ora = oracle.OracleIndex(words, **desc)
+        queries = [w[:-1] + "x" for w in words[::30]] + words[:40] + ["abc", "a" * q, "a" * (q - 1)]
+        qb, qo = oracle.pack_strings(queries)
+        for metric, a, k in (("jaccard", 0.3, 10), ("cosine", 0.5, 1024), ("dice", 0.2, 300)):
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k), ora.suggest_batch(qb, qo, metric, a, k), queries)
+    with pytest.raises(Exception):
+        gpu.suggest_batch(queries[:1], metric="jaccard", similarity=0.5, k=1025)
+    # query length: q = 3, wrap "$".."$": a string of L distinct-trigram runes has L n-grams
+    desc = dict(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "numbers", "$"))
+    base = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(rng.randint(100, 140))) for _ in range(300)]
+    gpu = NGramIndex(base, IndexDescription(**desc))
+    ora = oracle.OracleIndex(base, **desc)
+    exact = [d for d in base if len(ora.tokenize(d)) == 128][:5] or [base[0][:128]]
+    over = [d for d in base if len(ora.tokenize(d)) == 129][:5] or [base[0] + b"zq7"]
+    qb, qo = oracle.pack_strings(exact + over)
+    ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=5)
+    oi, os_, oc, _ = ora.suggest_batch(qb, qo, "jaccard", 0.5, 5)
+    n_ok = len(exact)
+    assert all(len(ora.tokenize(q)) <= 128 for q in exact) and all(len(ora.tokenize(q)) > 128 for q in over)
+    assert_same((ids[:n_ok], sc[:n_ok], cnt[:n_ok]), (oi[:n_ok], os_[:n_ok], oc[:n_ok]))
+    assert (cnt[n_ok:] == _lib.SG_COUNT_TOO_LONG).all()
