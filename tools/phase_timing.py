@@ -19,10 +19,28 @@ ap.add_argument("--similarity", type=float, default=0.5)
 ap.add_argument("--topk", type=int, default=10)
 ap.add_argument("--ngram", type=int, default=3)
 ap.add_argument("--dict-variant", default="uniform")
+ap.add_argument("--golden", default=None, choices=[None, "cars", "words"], help="use the reference's cars / words dictionary instead")
 args = ap.parse_args()
-blob, offs = synth.make_dict(args.dict_size, seed=1, skewed="skewed" in args.dict_variant, families=3 if "families" in args.dict_variant else 0)
-qb, qo = synth.make_queries(args.queries, blob, offs, seed=2)
-ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**dict(synth.DESCRIPTION, ngram_size=args.ngram)))
+if args.golden:
+    import lzma
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from conftest import CARS_DESC, WORDS_DESC
+    G = os.path.join(ROOT, "tests", "golden")
+    lines = open(os.path.join(G, "cars.dict"), "rb").read().splitlines() if args.golden == "cars" else lzma.open(os.path.join(G, "words.dict.xz")).read().splitlines()
+    rnd = np.random.RandomState(1)
+    qs = []
+    for i in rnd.randint(0, len(lines), size=args.queries):
+        w = bytearray(lines[int(i)])
+        if len(w) > 2:
+            w[int(rnd.randint(0, len(w)))] = ord("x")
+        qs.append(bytes(w))
+    qb, qo = oracle.pack_strings(qs)
+    ix = NGramIndex(lines, IndexDescription(**(CARS_DESC if args.golden == "cars" else WORDS_DESC)))
+else:
+    blob, offs = synth.make_dict(args.dict_size, seed=1, skewed="skewed" in args.dict_variant, families=3 if "families" in args.dict_variant else 0)
+    qb, qo = synth.make_queries(args.queries, blob, offs, seed=2)
+    ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**dict(synth.DESCRIPTION, ngram_size=args.ngram)))
 dev = torch.device("cuda", 0)
 prof = torch.zeros(2 * 4096 * 8, dtype=torch.int64, device=dev)
 L = _lib.lib()
