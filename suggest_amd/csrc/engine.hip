@@ -56,6 +56,7 @@ struct DeviceIndex {
   const uint32_t* dup_doc;     // [n_dups]
   const uint32_t* dup_mult;    // [n_dups] occurrences of the term in the doc (>= 2)
   const uint32_t* dup_docs;    // [n_dup_docs] ascending docIDs with any repeated term
+  const uint32_t* dup_bits;    // [ceil(n_docs/32)] bit d set: document d repeats a term (one load instead of a search per emitted doc)
   const uint32_t* extra_ts;    // [n_extra] term*S+segment of lists holding repeats, ascending
   const uint32_t* extra_cnt;   // [n_extra] raw length - stored length of that list
   const uint32_t* list_len;    // [n_terms*S] stored (de-duplicated) list lengths
@@ -854,21 +855,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       DBG_COUNT(5, 1)
       offer(d, overlap, w);
       if (ix.n_dup_docs) {                                  // dictionaries whose docs never repeat a term skip this
-        const uint32_t p = d_lower_bound_u32(ix.dup_docs, ix.n_dup_docs, d);
-        if (p < ix.n_dup_docs && ix.dup_docs[p] == d) emit_secondaries(d, w, T, fm0, fm1);
+        if ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u) emit_secondaries(d, w, T, fm0, fm1);
       }
     };
     auto flush_queue = [&]() {
+      PH(2)
       __syncthreads();
-      for (uint32_t c0 = 0; c0 < qn; c0 += 4) {                  // 4 candidates x A lists searched interleaved
+      // Lanes are (candidate, query term) pairs: with A <= 32 terms 64/gsz candidates are verified side by side, each lane
+      // running 4 of them interleaved (their dependent loads overlap) — up to 32 candidates per round of binary searches
+      // instead of 4.  Dictionaries of near-duplicates (product names) queue dozens of candidates per query.
+      const int gsz = a_rounds > 1 ? 64 : (A <= 8 ? 8 : A <= 16 ? 16 : A <= 32 ? 32 : 64), ngrp = 64 / gsz;
+      const int gi = lane / gsz, ti = lane - gi * gsz;
+      uint32_t* stage = cnt;                                      // verdicts: the counters are idle between groups
+      for (uint32_t c0 = 0; c0 < qn; c0 += 4u * (uint32_t)ngrp) {
         uint32_t qd[4], qw[4];
         bool ok[4];
         int ov[4] = {0, 0, 0, 0};
         uint64_t fmask[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
-        for (int j = 0; j < 4; j++) { ok[j] = c0 + j < qn; qd[j] = ok[j] ? cand[c0 + j] : 0u; qw[j] = ok[j] ? candw[c0 + j] : 0u; }
+        for (int j = 0; j < 4; j++) {
+          const uint32_t c = c0 + (uint32_t)(j * ngrp + gi);
+          ok[j] = c < qn; qd[j] = ok[j] ? cand[c] : 0u; qw[j] = ok[j] ? candw[c] : 0u;
+        }
         for (int r = 0; r < a_rounds; r++) {
-          const int i = r * 64 + lane;
+          const int i = r * 64 + ti;
           uint32_t lo[4], hi[4], n4[4];
           const uint32_t* pp[4];
 #pragma unroll
@@ -896,29 +906,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const bool found = lo[j] < n4[j] && pp[j][lo[j]] == qd[j];
-            const uint64_t fmj = ballot(found);
+            uint64_t fmj = ballot(found);
+            if (gsz < 64) fmj = (fmj >> (gi * gsz)) & ((1ull << gsz) - 1ull);   // this candidate's lanes: bit = term
             ov[j] += (int)popc64(fmj);
             if (r == 0) fmask[j][0] = fmj; else fmask[j][1] = fmj;
           }
         }
-        // stage the four verdicts in LDS (queue slots are consumed) so that emit() is instantiated once
+        // stage the verdicts in LDS (queue slots are consumed) so that emit() is instantiated once
         __syncthreads();
-        if (lane == 0) {
+        if (ti == 0) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            uint32_t* st = candw + SG_CAND_CAP + j * 8;           // staging area behind the queue
+            uint32_t* st = stage + (j * ngrp + gi) * 8;
             st[0] = qd[j]; st[1] = (uint32_t)ov[j]; st[2] = qw[j]; st[3] = ok[j] ? 1u : 0u;
             st[4] = (uint32_t)fmask[j][0]; st[5] = (uint32_t)(fmask[j][0] >> 32);
             st[6] = (uint32_t)fmask[j][1]; st[7] = (uint32_t)(fmask[j][1] >> 32);
           }
         }
         __syncthreads();
+        const int n_staged = 4 * ngrp;
 #pragma nounroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t* st = candw + SG_CAND_CAP + j * 8;
-          if (st[3]) emit(st[0], (int)st[1], (int)st[2], (uint64_t)st[4] | ((uint64_t)st[5] << 32), (uint64_t)st[6] | ((uint64_t)st[7] << 32));
+        for (int j = 0; j < n_staged; j++) {
+          const uint32_t* st = stage + j * 8;
+          const uint32_t s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5], s6 = st[6], s7 = st[7];
+          if (s3) emit(s0, (int)s1, (int)s2, (uint64_t)s4 | ((uint64_t)s5 << 32), (uint64_t)s6 | ((uint64_t)s7 << 32));
         }
       }
+      PH(4)
       qn = 0;
     };
 
@@ -1656,6 +1670,9 @@ int sg_index_upload(sg_index* ix, int device) {
     if ((rc = to_device(ix, ddoc.data(), ddoc.size(), &d.dup_doc))) return rc;
     if ((rc = to_device(ix, dmult.data(), dmult.size(), &d.dup_mult))) return rc;
     if ((rc = to_device(ix, ddocs.data(), ddocs.size(), &d.dup_docs))) return rc;
+    std::vector<uint32_t> dbits((size_t)(h.n_docs + 31) / 32 + 1, 0u);
+    for (uint32_t dd : ddocs) dbits[dd >> 5] |= 1u << (dd & 31u);
+    if ((rc = to_device(ix, dbits.data(), dbits.size(), &d.dup_bits))) return rc;
     if ((rc = to_device(ix, ets.data(), ets.size(), &d.extra_ts))) return rc;
     if ((rc = to_device(ix, ecnt.data(), ecnt.size(), &d.extra_cnt))) return rc;
     if ((rc = to_device(ix, h.list_len.data(), h.list_len.size(), &d.list_len))) return rc;

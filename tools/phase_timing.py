@@ -67,7 +67,7 @@ allp = prof.cpu().numpy().astype(np.float64).reshape(2, 4096, 8).sum(axis=1) / 6
 p = allp[0]
 cn = allp[1] / n_q
 print('per query: groups %.1f batches %.1f flag_events %.1f queued %.2f passes %.1f emitted %.2f skipped_chunks %.0f of %.0f' % tuple(cn))
-names = ["tokenize", "tile rows + segment stats", "group setup (merge, scan, geometry)", "clear counters", "chunk directory",
+names = ["tokenize", "tile rows + segment stats", "group setup (merge, scan, geometry)", "clear counters", "verify + emit queued candidates",
          "stream (loads + count)", "slow path (flagged)", "top-k sort + output"]
 tot = p.sum()
 print("cycles per query (wave-time, s_memtime): %.0f" % (tot / n_q))
