@@ -1258,37 +1258,130 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
 
       if (overflow) {
-        // More distinct candidates than the dedup set holds: second pass over the final counters;
-        // every remaining doc is handled exactly once, at its occurrence in the last list holding it
-        // (padding repeats a list's last doc inside its last chunk: skipped as equal neighbours).
+        // More distinct candidates than the dedup set holds: second pass over the final counters; every remaining doc
+        // is handled exactly once, at its occurrence in the last list holding it (padding repeats a list's last doc
+        // inside its last chunk: skipped as equal neighbours).  A matching doc is flagged once per list, so a query
+        // with hundreds of matches flags thousands of postings: they are collected 32 at a time and verified side by
+        // side (lanes = candidate x term, 4 interleaved per lane) — one site, so emit()/verify() keep one instance.
         __syncthreads();
-        for (int i = 0; i < A; i++) {
-          const int r = i >> 6, li = i & 63;
-          const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li);
+        uint32_t* p2_doc = dummy_w;                                // [32]  (the lanes' dummy counter words: idle outside the stream)
+        uint32_t* p2_w = dummy_w + 32;                             // [32]  segment within the tile
+        uint32_t* p2_list = candw + SG_CAND_CAP;                   // [32]  list the doc was met in (the staging words behind the queue)
+        uint32_t* p2_v = rowtab;                                   // [32]  verdict: overlap, or ~0 (not here / not this list)
+        uint32_t n_p2 = 0;
+        const int gsz = a_rounds > 1 ? 64 : (A <= 8 ? 8 : A <= 16 ? 16 : A <= 32 ? 32 : 64), ngrp = 64 / gsz;
+        const int gi = lane / gsz, ti = lane - gi * gsz;
+        for (int i = 0; i <= A; i++) {                             // i == A: nothing to stream, flushes what is left
+          const bool fin = i == A;
+          const int r = (i >> 6) & 1, li = i & 63;
+          const uint32_t s = fin ? 0u : readlane(r ? ls_r[1] : ls_r[0], li), n = fin ? 1u : readlane(r ? ln_r[1] : ln_r[0], li);
           for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t c = c0 + lane;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < n) v = post4[s + c];
-            const uint32_t dv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
+            if (!fin && c < n) v = post4[s + c];
+#pragma nounroll
             for (int e = 0; e < 4; e++) {
-              const uint32_t d = dv[e];
+              const uint32_t d = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+              const uint32_t dprev = e == 1 ? v.x : e == 2 ? v.y : v.z;
               bool flag = false;
-              if (c < n && !(e > 0 && d == dv[e > 0 ? e - 1 : 0])) {
-                const uint32_t b = d & ((1u << lg) - 1u);
-                const uint32_t now = u8 ? ((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
+              if (!fin && c < n && !(e > 0 && d == dprev)) {
+                const uint32_t bk = d & ((1u << lg) - 1u);
+                const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
                 flag = now >= (uint32_t)Teff;
               }
               uint64_t m = ballot(flag);
-              while (m) {
-                const int l = __builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t dd = readlane(d, l);
-                if (in_cand(dd)) continue;
-                int w, last;
-                uint64_t fm[2];
-                const int ov = verify(dd, (uint32_t)i, s + c0 + (uint32_t)l, &w, &last, fm);
-                if (last == i && dd >= lo_doc && dd < hi_doc) emit(dd, ov, w, fm[0], fm[1]);
+              for (bool more = true; more;) {
+                if (m) {
+                  const int l = __builtin_ctzll(m);
+                  m &= m - 1;
+                  const uint32_t dd = readlane(d, l);
+                  if (!in_cand(dd)) {
+                    const uint32_t chunk = s + c0 + (uint32_t)l;
+                    int w = g0;                                    // segment of dd: where list i holds `chunk`
+                    while (w < g1 && rows[i * stride + w + 1] <= chunk) w++;
+                    if (lane == 0) { p2_doc[n_p2] = dd; p2_w[n_p2] = (uint32_t)w; p2_list[n_p2] = (uint32_t)i; }
+                    n_p2++;
+                  }
+                }
+                more = m != 0;
+                if (n_p2 == 32u || (fin && e == 3 && !more && n_p2)) {
+                  __syncthreads();
+                  for (uint32_t b0 = 0; b0 < n_p2; b0 += 4u * (uint32_t)ngrp) {
+                    uint32_t qd[4], qw[4];
+                    bool ok[4];
+                    int ov[4] = {0, 0, 0, 0}, last[4] = {-1, -1, -1, -1};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                      const uint32_t cc = b0 + (uint32_t)(j * ngrp + gi);
+                      ok[j] = cc < n_p2; qd[j] = ok[j] ? p2_doc[cc] : 0u; qw[j] = ok[j] ? p2_w[cc] : 0u;
+                    }
+                    for (int rr = 0; rr < a_rounds; rr++) {
+                      const int it = rr * 64 + ti;
+                      uint32_t lo4[4], hi4[4], n4[4];
+                      const uint32_t* pp[4];
+#pragma unroll
+                      for (int j = 0; j < 4; j++) {
+                        lo4[j] = 0; hi4[j] = 0; n4[j] = 0; pp[j] = ix.postings;
+                        if (it < A && ok[j]) {
+                          const uint32_t s0 = rows[it * stride + qw[j]];
+                          n4[j] = (rows[it * stride + qw[j] + 1] - s0) * 4u;
+                          hi4[j] = n4[j];
+                          pp[j] = ix.postings + (uint64_t)s0 * 4;
+                        }
+                      }
+                      for (int step = 0; step < 32; step++) {
+                        bool act = false;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                          if (lo4[j] < hi4[j]) {
+                            const uint32_t mid = (lo4[j] + hi4[j]) >> 1;
+                            if (pp[j][mid] < qd[j]) lo4[j] = mid + 1; else hi4[j] = mid;
+                            act = true;
+                          }
+                        }
+                        if (!ballot(act)) break;
+                      }
+#pragma unroll
+                      for (int j = 0; j < 4; j++) {
+                        const bool found = lo4[j] < n4[j] && pp[j][lo4[j]] == qd[j];
+                        uint64_t fmj = ballot(found);
+                        if (gsz < 64) fmj = (fmj >> (gi * gsz)) & ((1ull << gsz) - 1ull);
+                        ov[j] += (int)popc64(fmj);
+                        if (fmj) last[j] = rr * 64 + 63 - __builtin_clzll(fmj);
+                      }
+                    }
+                    if (ti == 0) {
+#pragma unroll
+                      for (int j = 0; j < 4; j++) {
+                        const uint32_t cc = b0 + (uint32_t)(j * ngrp + gi);
+                        if (ok[j]) p2_v[cc] = (last[j] == (int)p2_list[cc] && qd[j] >= lo_doc && qd[j] < hi_doc) ? (uint32_t)ov[j] : 0xFFFFFFFFu;
+                      }
+                    }
+                  }
+                  __syncthreads();
+                  uint32_t dup_mask = 0;                           // docs that repeat a term: the full path below (rare)
+                  for (uint32_t cc = 0; cc < n_p2; cc++) {
+                    const uint32_t vv = p2_v[cc];
+                    if (vv == 0xFFFFFFFFu) continue;
+                    const uint32_t dd = p2_doc[cc];
+                    const int w = (int)p2_w[cc];
+                    if (ix.n_dup_docs && ((ix.dup_bits[dd >> 5] >> (dd & 31u)) & 1u)) { dup_mask |= 1u << cc; continue; }
+                    if ((int)vv < (int)readlane((uint32_t)seg_T, w)) continue;
+                    DBG_COUNT(5, 1)
+                    offer(dd, (int)vv, w);
+                  }
+                  while (dup_mask) {
+                    const uint32_t cc = (uint32_t)__builtin_ctz(dup_mask);
+                    dup_mask &= dup_mask - 1;
+                    const uint32_t dd = p2_doc[cc], jj = p2_list[cc];
+                    int w, lastl;
+                    uint64_t fm[2];
+                    const int ovl = verify(dd, jj, rows[jj * stride + p2_w[cc]], &w, &lastl, fm);
+                    emit(dd, ovl, w, fm[0], fm[1]);
+                  }
+                  n_p2 = 0;
+                  __syncthreads();
+                }
               }
             }
           }
