@@ -1216,29 +1216,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           }
           if (lane < 2 * SG_UNROLL) rowtab4[wn + lane] = make_uint4(0u, 0u, 0u, 0u);   // dead rows behind the last batch
           __syncthreads();
-          uint4 v[SG_UNROLL], vn[SG_UNROLL];
+          // The row loads are issued and awaited by hand (inline asm): the compiler's own wait-count insertion kept the
+          // "wait for this batch only, the next one stays in flight" schedule for a while and then — after an unrelated
+          // change elsewhere in the kernel — fell back to s_waitcnt vmcnt(0) right behind the prefetch (−5 % on the
+          // headline).  vmcnt counts in issue order, so vmcnt(4) with the 4 loads of the next batch behind them means
+          // "these four are here" whatever else is in flight.
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 v[SG_UNROLL], vn[SG_UNROLL];
           uint32_t live[SG_UNROLL], liven[SG_UNROLL];
           u32x16 was;
           uint32_t next_row = 0;
-          auto fetch = [&](uint4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL]) {
+          auto fetch = [&](u32x4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL]) {
 #pragma unroll
             for (int u = 0; u < SG_UNROLL; u++) {
               const uint4 t = rowtab4[next_row + (uint32_t)u];   // uniform address: one broadcast LDS read
               lv[u] = (uint32_t)lane < t.y ? 1u : 0u;
-              vv[u] = post4[t.x + min((uint32_t)lane, t.y ? t.y - 1 : 0u)];
+              const uint4* src = post4 + (t.x + min((uint32_t)lane, t.y ? t.y - 1 : 0u));
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vv[u]) : "v"(src) : "memory");
             }
             next_row += SG_UNROLL;
           };
           // ping-pong between two register sets: the next batch's loads are in flight while one is counted
-          auto process = [&](const uint4 (&pv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], uint32_t row0) {
+          auto process = [&](u32x4 (&qv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], uint32_t row0) {
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) :: "memory");
+            const uint4 pv[SG_UNROLL] = {make_uint4(qv[0].x, qv[0].y, qv[0].z, qv[0].w), make_uint4(qv[1].x, qv[1].y, qv[1].z, qv[1].w),
+                                         make_uint4(qv[2].x, qv[2].y, qv[2].z, qv[2].w), make_uint4(qv[3].x, qv[3].y, qv[3].z, qv[3].w)};
             uint64_t any = 0;
             if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
             else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
             DBG_COUNT(1, 1)
             if (any) { PH(5) flagged(pv, pl, was, rowtab4 + row0, Tm1); PH(6) }
           };
-          // fetches are unconditional (rows past the last are dead rows) so that the compiler can count the
-          // loads in flight: process(v) waits for v's four loads only (vmcnt(4)), not for the prefetched batch
+          // fetches are unconditional (rows past the last are dead rows: they load chunk 0): every process() has the four
+          // loads of the following batch behind its own
           const uint32_t n_batches = (wn + SG_UNROLL - 1) / SG_UNROLL;
           fetch(v, live);
           for (uint32_t bi = 0; bi < n_batches; bi += 2) {
@@ -1248,6 +1258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             fetch(v, live);
             process(vn, liven, (bi + 1) * SG_UNROLL);
           }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dead-row prefetch: nothing may be in flight into v / vn
         }
         PH(5)
         if (!(u8 && saturated)) break;
