@@ -16,7 +16,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def test_search_kernel_has_no_scratch_and_three_waves_per_simd(tmp_path):
     src = os.path.join(ROOT, "suggest_amd", "csrc", "engine.hip")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "engine.o")],
+                        "-Rpass-analysis=kernel-resource-usage", "-S", src, "-o", str(tmp_path / "engine.s")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = re.split(r"remark: Function Name: ", r.stderr)
@@ -30,3 +30,23 @@ def test_search_kernel_has_no_scratch_and_three_waves_per_simd(tmp_path):
     assert batch[0]["ScratchSize [bytes/lane]"] == 0, batch[0]
     assert batch[0]["Occupancy [waves/SIMD]"] >= 3, batch[0]
     assert batch[0]["VGPRs"] <= 168, batch[0]
+
+    # the stream loop keeps the next batch's four row loads in flight while it counts the current batch: the blocks
+    # that issue the LDS counter atomics wait with vmcnt(4), never with vmcnt(0), and touch no scratch
+    asm = open(tmp_path / "engine.s").read().split("\n")
+    start = next(i for i, l in enumerate(asm) if l.startswith("_ZN2sg18sg_search_kernel_tILb0ELb0"))
+    end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
+    blocks, cur = [], []
+    for l in asm[start:end]:
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            blocks.append(cur)
+            cur = []
+        elif l.startswith("\t") and not l.strip().startswith((";", ".")):
+            cur.append(l.strip())
+    blocks.append(cur)
+    hot = [b for b in blocks if sum("ds_add_rtn_u32" in x for x in b) >= 8]
+    assert len(hot) >= 2
+    for b in hot:
+        assert not any("scratch_" in x for x in b)
+        assert not any("s_waitcnt vmcnt(0)" in x for x in b), [x for x in b if "s_waitcnt" in x]
+    assert any("s_waitcnt vmcnt(4)" in x for b in hot for x in b)
