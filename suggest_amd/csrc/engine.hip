@@ -218,6 +218,30 @@ __device__ uint64_t d_pack_key(const DeviceIndex& ix, const uint32_t* runes, uin
   return k;
 }
 
+// ASCII symbol table held in registers: lane l keeps {sym, alpha} of runes l and 64 + l; a lookup is two ds_bpermute
+// (LDS crossbar, no memory access).  Every lane of the wave must take part in a lookup.
+struct AsciiTab { uint32_t lo, hi; };
+__device__ __forceinline__ AsciiTab d_ascii_tab(const DeviceIndex& ix, int lane) {
+  AsciiTab t;
+  t.lo = (uint32_t)ix.ascii_sym[lane] | ((uint32_t)ix.ascii_alpha[lane] << 8);
+  t.hi = (uint32_t)ix.ascii_sym[64 + lane] | ((uint32_t)ix.ascii_alpha[64 + lane] << 8);
+  return t;
+}
+// key of one n-gram of ASCII runes (all < 128), normalised like d_pack_key
+__device__ __forceinline__ uint64_t d_pack_key_ascii(const DeviceIndex& ix, const AsciiTab& tab, const uint32_t* runes, uint32_t n) {
+  uint64_t k = 0;
+  uint32_t len = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t r = runes[i] & 127u;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)tab.lo);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)tab.hi);
+    const uint32_t v = r < 64u ? a : b;
+    if (v >> 8) { k |= (uint64_t)(v & 0xFFu) << (8 * len); len++; }
+    else for (uint32_t p = 0; p < ix.n_pad; p++) { k |= (uint64_t)ix.pad_sym[p] << (8 * len); len++; }
+  }
+  return k;
+}
+
 __device__ uint64_t d_mix64(uint64_t k) {
   k ^= k >> 30; k *= 0xBF58476D1CE4E5B9ull;
   k ^= k >> 27; k *= 0x94D049BB133111EBull;
@@ -309,6 +333,26 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
     n_tok = 1;
   } else {
     const uint32_t G = Rt - q_n + 1;
+    bool big = false;                                          // (the wrap strings may hold non-ASCII runes)
+    for (uint32_t i = t0 + lane; i < t1; i += 64) big |= runes[i] > 127u;
+    if (ascii && q_n <= 3u && G <= 64u && ballot(big) == 0) {
+      // the common case in registers: a gram of <= 3 ASCII runes is a 21-bit fingerprint, appendUnique
+      // (ngram_tokenizer.go:46-54) is G wave-uniform readlanes, normalisation two ds_bpermute per rune
+      const AsciiTab tab = d_ascii_tab(ix, lane);
+      const uint32_t g = (uint32_t)lane;
+      const bool valid = g < G;
+      uint32_t w[3] = {0, 0, 0};
+      for (uint32_t t = 0; t < q_n; t++) w[t] = valid ? runes[t0 + g + t] : 0u;
+      const uint32_t fp = w[0] | (w[1] << 7) | (w[2] << 14) | (valid ? 1u << 21 : 0u);
+      bool dup = false;
+      for (uint32_t h = 0; h + 1 < G; h++) dup |= readlane(fp, (int)h) == fp && h < g;
+      const bool keep = valid && !dup;
+      const uint64_t m = ballot(keep);
+      const uint32_t rank = popc64(m & ((1ull << lane) - 1ull));
+      const uint64_t key = d_pack_key_ascii(ix, tab, w, q_n);    // every lane takes part in the lookups
+      if (keep && rank < SG_MAX_A) keys[rank] = key;
+      n_tok = popc64(m);
+    } else
     for (uint32_t base = 0; base < G; base += 64) {
       const uint32_t g = base + lane;
       const bool valid = g < G;
