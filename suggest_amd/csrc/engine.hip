@@ -286,16 +286,18 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
   const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete ? 0u : ix.n_wrap1;
   // ASCII?
   bool na = false;
-  for (uint32_t i = lane; i < qlen; i += 64) na |= q[i] >= 0x80;
+  for (uint32_t i = lane; i < qlen; i += 64) {            // one pass over the bytes: ASCII test and, optimistically, the runes
+    const uint32_t b = q[i];
+    na |= b >= 0x80;
+    if (n_w0 + i < SG_MAX_RUNES) runes[n_w0 + i] = (b - 'A' < 26u) ? b + 32u : b;
+  }
   const bool ascii = ballot(na) == 0;
   uint32_t R = 0, byte_len = 0;
   if (ascii) {
     R = n_w0 + qlen + n_w1;
     if (R > SG_MAX_RUNES) return -1;
-    for (uint32_t i = lane; i < R; i += 64) {
-      uint32_t r = i < n_w0 ? ix.wrap0[i] : (i < n_w0 + qlen ? (uint32_t)q[i - n_w0] : ix.wrap1[i - n_w0 - qlen]);
-      runes[i] = d_lower(ix, r);
-    }
+    if ((uint32_t)lane < n_w0) runes[lane] = d_lower(ix, ix.wrap0[lane]);
+    if ((uint32_t)lane < n_w1) runes[n_w0 + qlen + lane] = d_lower(ix, ix.wrap1[lane]);
     byte_len = qlen;
     for (uint32_t i = 0; i < n_w0; i++) byte_len += d_width(d_lower(ix, ix.wrap0[i]));
     for (uint32_t i = 0; i < n_w1; i++) byte_len += d_width(d_lower(ix, ix.wrap1[i]));
