@@ -1710,7 +1710,7 @@ const char* sg_last_error(void) { return g_err.c_str(); }
 
 static int build_any(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments, int device,
                      sg_index** out) {
-  if (!out || (!utf8 && n_docs) || !offs) { set_error("null argument"); return SG_E_INVALID; }
+  if (!out || !offs || (!utf8 && n_docs && offs[n_docs])) { set_error("null argument"); return SG_E_INVALID; }   // (all-empty documents need no bytes)
   auto* ix = new (std::nothrow) sg_index();
   if (!ix) return SG_E_NOMEM;
   ix->host.min_segments = min_segments;

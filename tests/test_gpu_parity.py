@@ -391,6 +391,9 @@ def test_device_index_build_is_identical_to_host_build(cars_lines, words_lines):
     odd = [b"", b"a", b"  ", "Привет мир".encode(), b"\xff\xfe bad \xc3", "İstanbul ǅ".encode(), b"ab", b"x" * 100, b"AAAAAAAA", b"abcabcabc"]
     cases.append((odd * 7, IndexDescription(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "russian", "numbers", "$"))))
     cases.append((odd * 3, IndexDescription(ngram_size=2, wrap=("^", "$"), pad="_", alphabet=("english", "_^$"))))
+    # an empty pad turns n-grams of foreign runes into the EMPTY term (key 0) and makes most documents repeat terms
+    cases.append(([b"ab - c", b"--- --", b"a-b", b"   ", b"abc", b"- -", b"cab cab"] * 40,
+                  IndexDescription(ngram_size=3, wrap=("", ""), pad="", alphabet=("english", "numbers"))))
     for docs, desc in cases:
         host = NGramIndex(docs, desc, upload=False)
         dev = NGramIndex(docs, desc, upload=False, build="device")
