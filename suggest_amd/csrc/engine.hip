@@ -1103,10 +1103,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         return ballot(seen) != 0;
       };
       auto on_flag = [&](uint32_t dd, uint32_t jj, uint32_t chunk) {   // dd flagged in list jj at posting-store chunk
-        if (u8) {                                              // a saturating u8 counter would carry into its neighbour
-          const uint32_t b = dd & ((1u << lg) - 1u);       // u8 bucket = low lg bits of the docID
-          if (((cnt[b >> 2] >> ((b & 3u) << 3)) & 0xFFu) >= 250u) saturated = true;
-        }
         if (in_cand(dd)) return;
         if (qn == SG_CAND_CAP) { overflow = true; return; }
         int w = g0;                                            // segment of dd: where list jj holds `chunk`
@@ -1128,6 +1124,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         uint32_t fl = 0;
 #pragma unroll
         for (int ue = 0; ue < 4 * SG_UNROLL; ue++) fl |= ((live[ue >> 2] && was[ue] >= Tm1) ? 1u : 0u) << ue;
+        if (u8) {
+          // a u8 counter about to wrap would carry into its neighbour and — worse — undercount its own bucket.  Every
+          // increment returns the value it found, and a counter passes through every value on its way up, so "some
+          // posting found >= 250" is seen before any wrap (reading the counter afterwards is not: identical lists of a
+          // query that repeats a term can push one bucket past 255 within a single batch).
+          uint32_t hot = 0;
+#pragma unroll
+          for (int ue = 0; ue < 4 * SG_UNROLL; ue++) hot |= (live[ue >> 2] && was[ue] >= 250u) ? 1u : 0u;
+          if (ballot(hot != 0)) saturated = true;
+        }
         uint64_t lanes = ballot(fl != 0);
         while (lanes) {
           const int l = __builtin_ctzll(lanes);

@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle: bit-exact ids, order, scores."""
+import os
+
 import numpy as np
 import pytest
 
@@ -477,3 +479,17 @@ def test_limits_long_ngrams_max_k_and_query_length():
     assert all(len(ora.tokenize(q)) <= 128 for q in exact) and all(len(ora.tokenize(q)) > 128 for q in over)
     assert_same((ids[:n_ok], sc[:n_ok], cnt[:n_ok]), (oi[:n_ok], os_[:n_ok], oc[:n_ok]))
     assert (cnt[n_ok:] == _lib.SG_COUNT_TOO_LONG).all()
+
+
+@pytest.mark.parametrize("seed", [300004, 700812])
+def test_fuzz_regressions(seed, monkeypatch):
+    """Trials of tools/fuzz_parity.py that found bugs: 300004 — device builder and the empty term (empty pad); 700812 — a u8
+    counter wrapping within one batch (a query repeating one term 33 times, 2 KB of counters) went unnoticed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    t = fz.make_trial(seed)
+    for name, value in t["env"].items():
+        monkeypatch.setenv(name, value)
+    assert fz.run_trial(t) == []

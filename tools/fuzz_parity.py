@@ -1,32 +1,29 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity hunt (GPU box only): random descriptions, dictionaries with heavy repetition (ties,
-repeated terms, overflowing groups), random metrics / k / tuning knobs, suggest + autocomplete.  Prints the seed of any
-mismatch.   python tools/fuzz_parity.py --seconds 300 [--seed 1]"""
+repeated terms, overflowing groups), random metrics / k / tuning knobs / builder, suggest + autocomplete.
+
+  python tools/fuzz_parity.py --seconds 300 [--seed 1]       hunt; prints the seed of any mismatch
+  python tools/fuzz_parity.py --replay SEED [NAME=VALUE ...]  replay one trial verbosely (SG_* knobs, build=, k=, only=ROW)
+tests/test_gpu_parity.py::test_fuzz_regressions replays the seeds that found bugs."""
 import argparse, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import torch  # noqa: F401
-import oracle
-from suggest_amd import IndexDescription, NGramIndex
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--seconds", type=float, default=120)
-ap.add_argument("--seed", type=int, default=1)
-args = ap.parse_args()
-t_end = time.time() + args.seconds
-trial, bad = 0, 0
-while time.time() < t_end:
-    seed = args.seed * 100000 + trial
-    trial += 1
-    t_trial = time.time()
+KNOBS = (("SG_LOG2_CNT", ["9", "10", "11", "12"]), ("SG_T_FLOOR", ["2", "4", "10", "30"]), ("SG_FILTER_LEVEL", ["0", "2", "3"]),
+         ("SG_SPLIT_CHUNKS", ["0", "1", "8", "65536"]))
+
+
+def make_trial(seed):
+    """-> None (description not usable) or dict(desc, docs, queries, env, build, searches [(metric, a, k)], limit)"""
+    import oracle
     rng = random.Random(seed)
     q = rng.choice([1, 2, 2, 3, 3, 3, 4, 5])
     alpha = rng.choice([("english",), ("english", "numbers"), ("ab", "$"), ("russian", "english", "numbers", "$"), ("abc", "-")])
     wrap = rng.choice([("$", "$"), ("^", "$"), ("", ""), (" ", " "), ("$$", "")])
     pad = rng.choice(["$", "_", ""]) if q <= 4 else "$"
     if q * max(1, len(pad)) > 8:
-        continue
+        return None
     syms = rng.choice(["ab", "abc -", "abcdefgh 12", "абвгд ёab", "AbC.dE f", "abcdefghijklmnopqrstuvwxyz"])
     n_docs = rng.choice([1, 5, 50, 400, 3000, 20000])
     max_len = rng.choice([6, 14, 30, 60])
@@ -40,42 +37,94 @@ while time.time() < t_end:
         docs.append("".join(w))
     desc = dict(ngram_size=q, wrap=wrap, pad=pad, alphabet=alpha)
     if len(oracle.OracleIndex([docs[0]], **desc).tokenize(docs[0])) == 0:
-        docs[0] = "abcabcab"
+        docs[0] = "abcabcab"      # the reference panics if the FIRST document has no tokens (indexer_writer.go:70)
         if len(oracle.OracleIndex([docs[0]], **desc).tokenize(docs[0])) == 0:
-            continue
-    for name, choices in (("SG_LOG2_CNT", ["9", "10", "11", "12"]), ("SG_T_FLOOR", ["2", "4", "10", "30"]), ("SG_FILTER_LEVEL", ["0", "2", "3"]),
-                          ("SG_SPLIT_CHUNKS", ["0", "1", "8", "65536"])):
-        os.environ[name] = rng.choice(choices)
-    try:
-        gpu = NGramIndex(docs, IndexDescription(**desc), build=rng.choice(["host", "device"]) if max_len <= 60 else "host")
-    except Exception as exc:  # unsupported description (key does not fit) is fine; anything else is not
-        if "fit" in str(exc) or "UNSUPPORTED" in str(exc) or "-2" in str(exc):
-            continue
-        raise
-    ora = oracle.OracleIndex(docs, **desc)
+            return None
+    env = {name: rng.choice(choices) for name, choices in KNOBS}
+    build = rng.choice(["host", "device"]) if max_len <= 60 else "host"
     queries = [rng.choice(docs) for _ in range(30)] + ["".join(rng.choice(syms) for _ in range(rng.randint(0, max_len + 6))) for _ in range(30)]
     queries += [d[:rng.randint(0, len(d))] + rng.choice(syms) + d[rng.randint(0, len(d)):] for d in rng.sample(docs, min(20, len(docs)))]
-    qb, qo = oracle.pack_strings(queries)
+    searches = []
     for _ in range(3):
         metric = rng.choice(["jaccard", "cosine", "dice", "overlap", "exact"])
         a = 1.0 if metric == "exact" else rng.choice([0.15, 0.3, 0.5, 0.7, 0.9, 1.0])
-        k = rng.choice([1, 2, 5, 10, 64, 65, 300])
+        searches.append((metric, a, rng.choice([1, 2, 5, 10, 64, 65, 300])))
+    return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=rng.choice([1, 7, 100]), syms=syms)
+
+
+def run_trial(t, verbose=False, only=None, k_override=None):
+    """-> list of mismatch descriptions (empty = parity)"""
+    import oracle
+    from suggest_amd import IndexDescription, NGramIndex
+    os.environ.update(t["env"])
+    try:
+        gpu = NGramIndex(t["docs"], IndexDescription(**t["desc"]), build=t["build"])
+    except Exception as exc:      # a description whose terms do not fit the 64-bit key is refused, not answered
+        if "fit" in str(exc) or "-2" in str(exc):
+            return []
+        raise
+    ora = oracle.OracleIndex(t["docs"], **t["desc"])
+    queries = t["queries"] if only is None else [t["queries"][only]]
+    qb, qo = oracle.pack_strings(queries)
+    out = []
+    for metric, a, k in t["searches"]:
+        k = k_override or k
         ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k)
         oi, os_, oc, _ = ora.suggest_batch(qb, qo, metric, a, k)
         valid = (np.arange(k)[None, :] < np.minimum(oc, k)[:, None]) & (oc < 0xFFFFFFF0)[:, None]
-        if not (np.array_equal(cnt, oc) and np.array_equal(ids[valid], oi[valid]) and np.array_equal(sc.view(np.uint64)[valid], os_.view(np.uint64)[valid])):
-            bad += 1
-            rows = np.nonzero((cnt != oc) | (valid & ((ids != oi) | (sc.view(np.uint64) != os_.view(np.uint64)))).any(axis=1))[0]
-            print("MISMATCH seed %d: %s %s a=%.2f k=%d env=%s rows=%s q=%r" % (seed, desc, metric, a, k, {n: os.environ[n] for n in ("SG_LOG2_CNT", "SG_T_FLOOR", "SG_FILTER_LEVEL", "SG_SPLIT_CHUNKS")}, rows[:5], queries[int(rows[0])]), flush=True)
-    limit = rng.choice([1, 7, 100])
-    ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=limit)
-    oi, oc, _ = ora.autocomplete_batch(qb, qo, limit)
-    valid = np.arange(limit)[None, :] < np.minimum(oc, limit)[:, None]
+        rows = np.nonzero((cnt != oc) | (valid & ((ids != oi) | (sc.view(np.uint64) != os_.view(np.uint64)))).any(axis=1))[0]
+        if verbose:
+            print(metric, a, k, "differing rows:", rows[:10])
+        if rows.size:
+            r = int(rows[0])
+            g = list(zip(ids[r, :int(min(cnt[r], k))].tolist(), sc[r, :int(min(cnt[r], k))].tolist()))
+            o = list(zip(oi[r, :int(min(oc[r], k))].tolist(), os_[r, :int(min(oc[r], k))].tolist()))
+            first = next((i for i in range(min(len(g), len(o))) if g[i] != o[i]), min(len(g), len(o)))
+            out.append("%s a=%.2f k=%d rows=%s query=%r (%d tokens) counts gpu/oracle %d/%d, first difference at rank %d: gpu %s oracle %s"
+                       % (metric, a, k, rows[:5].tolist(), queries[r], len(ora.tokenize(queries[r])), int(cnt[r]), int(oc[r]), first,
+                          g[first:first + 2], o[first:first + 2]))
+    ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=t["limit"])
+    oi, oc, _ = ora.autocomplete_batch(qb, qo, t["limit"])
+    valid = np.arange(t["limit"])[None, :] < np.minimum(oc, t["limit"])[:, None]
     if not (np.array_equal(cnt, oc) and np.array_equal(ids[valid], oi[valid])):
-        bad += 1
-        print("MISMATCH (autocomplete) seed %d: %s limit=%d" % (seed, desc, limit), flush=True)
+        out.append("autocomplete limit=%d" % t["limit"])
     gpu.close()
-    if time.time() - t_trial > 5:
-        print("slow trial: seed %d took %.1f s: %s, %d docs, syms %r" % (seed, time.time() - t_trial, desc, n_docs, syms), flush=True)
-print("fuzz: %d trials, %d mismatches" % (trial, bad))
-sys.exit(1 if bad else 0)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--replay", type=int, default=None)
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    if args.replay is not None:
+        over = dict(x.split("=") for x in args.overrides)
+        t = make_trial(args.replay)
+        t["env"].update({k: v for k, v in over.items() if k.startswith("SG_")})
+        t["build"] = over.get("build", t["build"])
+        print(t["desc"], len(t["docs"]), "docs", t["env"], "build", t["build"])
+        for m in run_trial(t, verbose=True, only=int(over["only"]) if "only" in over else None, k_override=int(over["k"]) if "k" in over else None):
+            print("MISMATCH", m)
+        return
+    t_end, trial, bad = time.time() + args.seconds, 0, 0
+    while time.time() < t_end:
+        seed = args.seed * 100000 + trial
+        trial += 1
+        t0 = time.time()
+        t = make_trial(seed)
+        if t is None:
+            continue
+        for m in run_trial(t):
+            bad += 1
+            print("MISMATCH seed %d: %s env=%s build=%s: %s" % (seed, t["desc"], t["env"], t["build"], m), flush=True)
+        if time.time() - t0 > 5:
+            print("slow trial: seed %d took %.1f s: %s, %d docs, syms %r" % (seed, time.time() - t0, t["desc"], len(t["docs"]), t["syms"]), flush=True)
+    print("fuzz: %d trials, %d mismatches" % (trial, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
