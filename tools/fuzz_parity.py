@@ -14,7 +14,7 @@ KNOBS = (("SG_LOG2_CNT", ["9", "10", "11", "12"]), ("SG_T_FLOOR", ["2", "4", "10
          ("SG_SPLIT_CHUNKS", ["0", "1", "8", "65536"]))
 
 
-def make_trial(seed):
+def make_trial(seed, scale=1):
     """-> None (description not usable) or dict(desc, docs, queries, env, build, searches [(metric, a, k)], limit)"""
     import oracle
     rng = random.Random(seed)
@@ -25,7 +25,7 @@ def make_trial(seed):
     if q * max(1, len(pad)) > 8:
         return None
     syms = rng.choice(["ab", "abc -", "abcdefgh 12", "абвгд ёab", "AbC.dE f", "abcdefghijklmnopqrstuvwxyz"])
-    n_docs = rng.choice([1, 5, 50, 400, 3000, 20000])
+    n_docs = rng.choice([1, 5, 50, 400, 3000, 20000]) * scale
     max_len = rng.choice([6, 14, 30, 60])
     base = ["".join(rng.choice(syms) for _ in range(rng.randint(0, max_len))) for _ in range(max(1, n_docs // rng.choice([1, 1, 4, 20])))]
     docs = []
@@ -97,12 +97,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--replay", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=1, help="multiplies the dictionary sizes (1 .. 20 000 documents)")
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()
     import torch  # noqa: F401
     if args.replay is not None:
         over = dict(x.split("=") for x in args.overrides)
-        t = make_trial(args.replay)
+        t = make_trial(args.replay, args.scale)
         t["env"].update({k: v for k, v in over.items() if k.startswith("SG_")})
         t["build"] = over.get("build", t["build"])
         print(t["desc"], len(t["docs"]), "docs", t["env"], "build", t["build"])
@@ -114,7 +115,7 @@ def main():
         seed = args.seed * 100000 + trial
         trial += 1
         t0 = time.time()
-        t = make_trial(seed)
+        t = make_trial(seed, args.scale)
         if t is None:
             continue
         for m in run_trial(t):
