@@ -1858,6 +1858,9 @@ int sg_index_upload(sg_index* ix, int device) {
     const double terms_per_doc = h.n_docs ? (double)h.n_postings_raw / (double)h.n_docs : 0.0;
     ix->est_query_chunks = s1 > 0 ? terms_per_doc * s2 / s1 : 0.0;
     ix->terms_per_doc = terms_per_doc;
+    // long-list indexes (q = 2, skewed symbols: megabytes of postings per query) run mostly docID-range passes: twice
+    // the counter words halve the passes and more than pay for the lost occupancy (skewed 10M: +10 %, q=2: +3 %)
+    if (!getenv("SG_LOG2_CNT") && ix->est_query_chunks > 131072.0) ix->log2_cnt = 12;
     if (getenv("SG_VERBOSE")) fprintf(stderr, "[suggest_hip] terms/doc %.2f, expected query volume %.0f chunks, longest term %.0f chunks\n", terms_per_doc, ix->est_query_chunks, ix->max_term_chunks);
   }
   env = getenv("SG_SPLIT_CHUNKS");            // tuning knob: fewest 16-byte chunks per part of a split query (default 65536; 0 = off)
@@ -1866,9 +1869,9 @@ int sg_index_upload(sg_index* ix, int device) {
   if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->filter_level = (uint32_t)v; }
   env = getenv("SG_PARTS_CNT_BONUS");         // tuning knob: log2 of how much larger the parts launch's counter array is
   if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->parts_cnt_bonus = (uint32_t)v; }
-  HIP_TRY(hipFuncSetAttribute((const void*)sg_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes(std::min<uint32_t>(ix->log2_cnt + ix->parts_cnt_bonus, 14u))));
-  HIP_TRY(hipFuncSetAttribute((const void*)sg_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(ix->log2_cnt)));
+  // (the attribute belongs to the function, not to the index: always the largest size any index may ask for)
+  HIP_TRY(hipFuncSetAttribute((const void*)sg_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(14)));
+  HIP_TRY(hipFuncSetAttribute((const void*)sg_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(14)));
   {  // per-launch scratch comes from the device's stream-ordered pool: keep freed blocks instead of returning them
     hipMemPool_t pool;
     uint64_t keep = ~0ull;
