@@ -193,9 +193,15 @@ def main():
         total_q = world * n_q * args.steps
         avg_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        metric_name = "fuzzy queries/sec (k=%d, %s\u2265%.2g) on %s-string dict" % (k, args.metric.capitalize(), args.similarity, _human(args.dict_size))
+        try:      # the headline workload carries BASELINE.json's metric string verbatim (its "HBM GB/s fraction" half is `roofline.frac`)
+            base_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+            if base_metric.startswith(metric_name) and args.ngram == 3 and args.dict_variant == "uniform":
+                metric_name = base_metric
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
-            "metric": "fuzzy queries/sec (k=%d, %s>=%.2g) on %s-string dict" % (k, args.metric.capitalize(), args.similarity,
-                                                                              _human(args.dict_size)),
+            "metric": metric_name,
             "value": total_q / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
