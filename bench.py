@@ -64,11 +64,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    # test hooks (1-GPU box): SG_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0, SG_BENCH_BACKEND=gloo avoids RCCL's
+    # one-rank-per-GPU rule — exercises the N>1 control flow (barriers, max-over-ranks, per-rank batches), not the links
+    if os.environ.get("SG_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def log(*a):
         if rank == 0:
@@ -130,7 +138,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
