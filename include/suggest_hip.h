@@ -82,8 +82,18 @@ int sg_index_build_ex(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs
  * pkg/index/codec.go:39-51) — into the same CSR.  `desc` must be the IndexDescription the files were built with. */
 int sg_index_load_reference(const char* hd_path, const char* dl_path, const sg_desc* desc, sg_index** out);
 
-/* Copies the CSR index into the HBM of `device` (one replica per GPU; per-process). */
+/* Copies the CSR index into the HBM of `device` (one replica per GPU; per-process).  The first upload makes the primary
+ * replica (the one sg_suggest_batch / sg_autocomplete_batch run on); uploading to a device that already holds a replica is
+ * a no-op.  A device-built index (sg_index_build_device) whose first upload goes to the building device keeps the posting
+ * store where the build left it (no D2H + H2D round trip).  Safe to call concurrently. */
 int sg_index_upload(sg_index* index, int device);
+
+/* Multi-GPU (BASELINE north_star: "query batches shard naturally across the 8 GPUs of one node"): ONE host
+ * build, one replica per listed device.  A device listed j times ends up with j replicas (only useful to exercise the
+ * multi-replica paths on a one-GPU box).  Replicas already present are kept. */
+int sg_index_replicate(sg_index* index, const int* devices, uint32_t n_devices);
+/* Devices of the replicas in upload order (primary first): fills up to cap entries, returns their number. */
+uint32_t sg_index_replicas(sg_index* index, int* out_devices, uint32_t cap);
 
 /* nGramSuggester.Suggest for a batch of queries — pkg/suggest/suggester.go:46-131 with
  * newFuzzyCollectorManager(k) (collector.go:143-149): tokenise, window [MinY,MaxY], per segment
@@ -94,8 +104,8 @@ int sg_index_upload(sg_index* index, int device);
 int sg_suggest_batch(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
                      double similarity, uint32_t k, uint32_t* out_ids, double* out_scores, uint32_t* out_counts);
 
-/* Same, on buffers already resident in the HBM of the index's device; enqueued on `stream`
- * (a hipStream_t, NULL = the legacy default stream) and asynchronous w.r.t. the host. */
+/* Same, on buffers already resident in HBM; enqueued on `stream` (a hipStream_t of that device, NULL = the legacy default
+ * stream) and asynchronous w.r.t. the host.  With several replicas the one on the device that owns d_q_offs runs it. */
 int sg_suggest_batch_device(sg_index* index, const void* d_q_utf8, const void* d_q_offs, uint32_t n_q, int metric,
                             double similarity, uint32_t k, void* d_out_ids, void* d_out_scores, void* d_out_counts,
                             void* stream);
@@ -107,6 +117,25 @@ int sg_autocomplete_batch(sg_index* index, const uint8_t* q_utf8, const uint64_t
                           uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
 int sg_autocomplete_batch_device(sg_index* index, const void* d_q_utf8, const void* d_q_offs, uint32_t n_q,
                                  uint32_t limit, void* d_out_ids, void* d_out_counts, void* stream);
+
+/* sg_suggest_batch / sg_autocomplete_batch over every replica of the index: the batch is cut into contiguous slices, one per
+ * replica, every slice is in flight (copy in, launch, copy out on that device's stream) before the first is awaited, and
+ * rows land in caller order.  No collective: queries are independent and the index is read-only.  With
+ * one replica these are the plain calls. */
+int sg_suggest_batch_multi(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
+                           double similarity, uint32_t k, uint32_t* out_ids, double* out_scores, uint32_t* out_counts);
+int sg_autocomplete_batch_multi(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                                uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
+
+/* Suggester.Suggest / Autocomplete.Autocomplete as the reference calls them: ONE query per call, from many goroutines at
+ * once (pkg/suggest/suggester.go:46, autocomplete.go:40, service_test.go:36-79).  Blocking; concurrent callers are
+ * coalesced: the request is queued and dispatcher threads (SG_COALESCE_LANES per replica, default 2) run whatever is
+ * pending with the same (metric, similarity, k) as one launch — no timer, an idle engine serves a lone request at once.
+ * out_ids / out_scores hold k entries, *out_count the number written (or an SG_COUNT_* flag, nothing written). */
+int sg_suggest_one(sg_index* index, const uint8_t* q_utf8, uint32_t len, int metric, double similarity, uint32_t k,
+                   uint32_t* out_ids, double* out_scores, uint32_t* out_count);
+int sg_autocomplete_one(sg_index* index, const uint8_t* q_utf8, uint32_t len, uint32_t limit, uint32_t* out_ids,
+                        uint32_t* out_count);
 
 /* Reference counting: the Go shim retains while a query is in flight and releases from a
  * finalizer, mirroring the reference's mmap release (pkg/index/index_reader.go:49-51). */

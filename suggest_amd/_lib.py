@@ -22,6 +22,7 @@ EXPORTS = [
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch",
+    "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
 
@@ -60,7 +61,14 @@ def lib():
     L.sg_index_digest.argtypes = [vp, vp]
     L.sg_index_load_reference.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SgDesc), C.POINTER(vp)]
     L.sg_index_upload.argtypes = [vp, i32]
+    L.sg_index_replicate.argtypes = [vp, vp, u32]
+    L.sg_index_replicas.argtypes = [vp, vp, u32]
+    L.sg_index_replicas.restype = u32
     L.sg_suggest_batch.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
+    L.sg_suggest_batch_multi.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
+    L.sg_autocomplete_batch_multi.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.sg_suggest_one.argtypes = [vp, C.c_char_p, u32, i32, dbl, u32, vp, vp, vp]
+    L.sg_autocomplete_one.argtypes = [vp, C.c_char_p, u32, u32, vp, vp]
     L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
     L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]

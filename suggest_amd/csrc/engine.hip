@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <functional>
@@ -1517,824 +1520,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
 
+
 #define sg_search_kernel sg_search_kernel_t<false, false>
 #define sg_parts_kernel sg_search_kernel_t<true, false>
 #define sg_lm_kernel sg_search_kernel_t<false, true>
 
-// ------------------------------------------------------------------------------------------
-// host side: handle, upload, launches, C ABI
-// ------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-void set_error(const std::string& m) { g_err = m; }
-
 }  // namespace sg
 
-using namespace sg;
-
-struct sg_index {
-  HostIndex host;
-  std::atomic<int> refs{1};
-  int device = -1;
-  bool uploaded = false;
-  DeviceIndex dix{};
-  std::vector<void*> allocs;
-  uint64_t device_bytes = 0;
-  uint32_t log2_cnt = 11;
-  int t_floor = 10;
-  uint32_t filter_level = 2;
-  uint32_t split_chunks = 65536;   // 1 MiB of postings per part at least; 0 = never split a query
-  double terms_per_doc = 0;
-  double max_term_chunks = 0;      // chunks of the longest term (all segments)
-  uint32_t parts_cnt_bonus = 2;    // log2 of the counter-array growth of the parts launch for small batches
-  uint32_t parts_grid = 3072;      // wavefronts of the second launch (three per SIMD are resident)
-  double est_query_chunks = 0;     // expected 16-byte chunks of postings a query's terms hold (size-biased mean list x terms per doc)
-};
-
-#define HIP_TRY(expr)                                                                   \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess) {                                                             \
-      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
-      return SG_E_HIP;                                                                  \
-    }                                                                                   \
-  } while (0)
-
-struct sg_lm {
-  HostLM host;
-  std::atomic<int> refs{1};
-  std::mutex mu;                       // guards the lazy upload
-  int device = -1;
-  uint64_t* d_values = nullptr;        // every level's (word << 32 | count), level after level
-  std::vector<uint32_t> level_base;    // first entry of level l in d_values
-};
-
-static void* g_prof_buf = nullptr;   // SG_PHASE_TIMING builds only (sg_debug_set_prof)
-
-namespace {
-
-template <class T>
-int to_device(sg_index* ix, const T* src, size_t n, const T** out) {
-  void* p = nullptr;
-  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
-  HIP_TRY(hipMalloc(&p, bytes));
-  ix->allocs.push_back(p);
-  ix->device_bytes += bytes;
-  if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
-  *out = (const T*)p;
-  return SG_OK;
-}
-
-struct LowerPair { uint32_t from, to; };
-const LowerPair kLowerPairs[] = {
-#include "unicode_lower.inc"
-};
-
-// symbol tables, lower-case table, wrap and pad of the description: what the device tokeniser reads
-int upload_description(sg_index* ix, DeviceIndex& d) {
-  const HostIndex& h = ix->host;
-  int rc;
-  if ((rc = to_device(ix, h.sym.ascii_sym, 128, &d.ascii_sym))) return rc;
-  if ((rc = to_device(ix, h.sym.ascii_alpha, 128, &d.ascii_alpha))) return rc;
-  if ((rc = to_device(ix, h.sym.na_rune.data(), h.sym.na_rune.size(), &d.na_rune))) return rc;
-  if ((rc = to_device(ix, h.sym.na_sym.data(), h.sym.na_sym.size(), &d.na_sym))) return rc;
-  if ((rc = to_device(ix, h.sym.na_alpha.data(), h.sym.na_alpha.size(), &d.na_alpha))) return rc;
-  std::vector<uint32_t> lf, lt;
-  for (const auto& p : kLowerPairs) { lf.push_back(p.from); lt.push_back(p.to); }
-  if ((rc = to_device(ix, lf.data(), lf.size(), &d.lower_from))) return rc;
-  if ((rc = to_device(ix, lt.data(), lt.size(), &d.lower_to))) return rc;
-  d.n_na = (uint32_t)h.sym.na_rune.size();
-  d.n_lower = (uint32_t)lf.size();
-  d.q = h.q;
-  d.n_wrap0 = (uint32_t)h.wrap0.size();
-  d.n_wrap1 = (uint32_t)h.wrap1.size();
-  for (size_t i = 0; i < h.wrap0.size(); i++) d.wrap0[i] = h.wrap0[i];
-  for (size_t i = 0; i < h.wrap1.size(); i++) d.wrap1[i] = h.wrap1[i];
-  d.n_pad = h.sym.n_pad;
-  memcpy(d.pad_sym, h.sym.pad_sym, 8);
-  return SG_OK;
-}
-
-size_t lds_bytes(uint32_t log2_cnt) {
-  size_t words = (1u << log2_cnt) + SG_MAX_A + SG_ROWS_CAP + SG_CAND_CAP * 2 + 32 + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + 64 +
-                 SG_K_LDS + SG_K_LDS * 2;
-  return words * 4;
-}
-
-int check_search_args(sg_index* index, uint32_t k, bool need_alpha, double similarity, int metric) {
-  if (!index) { set_error("null index"); return SG_E_INVALID; }
-  if (!index->uploaded) { set_error("index not uploaded: call sg_index_upload first"); return SG_E_NOT_UPLOADED; }
-  if (k == 0) { set_error("topK should be greater or equal to 1"); return SG_E_INVALID; }       // search.go:20-22
-  if (k > SG_MAX_TOPK) { set_error("topK above SG_MAX_TOPK"); return SG_E_INVALID; }
-  if (need_alpha) {
-    if (!(similarity > 0 && similarity <= 1)) { set_error("similarity shouble be in (0.0, 1.0]"); return SG_E_INVALID; }  // search.go:24-26
-    if (metric < SG_JACCARD || metric > SG_OVERLAP) { set_error("unknown metric"); return SG_E_INVALID; }
-  }
-  return SG_OK;
-}
-
-struct LmRanges { const uint64_t* values; const uint32_t *from, *to; };   // device pointers (spellchecker mode)
-
-int launch(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, int metric, double similarity, uint32_t k,
-           int autocomplete, void* d_ids, void* d_scores, void* d_counts, hipStream_t stream, const LmRanges* lm = nullptr) {
-  if (n_q == 0) return SG_OK;
-  BatchArgs a{};
-  a.ix = index->dix;
-  if (lm) { a.lm_values = lm->values; a.lm_from = lm->from; a.lm_to = lm->to; }
-  a.q_blob = (const uint8_t*)d_q;
-  a.q_offs = (const uint64_t*)d_offs;
-  a.out_ids = (uint32_t*)d_ids;
-  a.out_scores = (double*)d_scores;
-  a.out_counts = (uint32_t*)d_counts;
-  a.alpha = similarity;
-  a.n_q = n_q;
-  a.k = k;
-  a.metric = metric;
-  a.autocomplete = autocomplete;
-  a.log2_cnt = index->log2_cnt;
-  a.t_floor = index->t_floor;
-  a.filter_level = index->filter_level;
-  a.prof = (unsigned long long*)g_prof_buf;
-#ifdef SG_PHASE_TIMING
-  { const char* e = getenv("SG_DEBUG_SKIP"); a.dbg_skip = e ? (uint32_t)atoi(e) : 0u; }
-#endif
-  int prev_dev = -1;   // the launch goes to the index's device whatever the calling thread's current device is
-  HIP_TRY(hipGetDevice(&prev_dev));
-  if (prev_dev != index->device) HIP_TRY(hipSetDevice(index->device));
-  struct Restore { int d, want; ~Restore() { if (d != want) (void)hipSetDevice(d); } } restore{prev_dev, index->device};
-  void* scratch = nullptr;
-  if (k > SG_K_LDS) {  // top-k working rows in HBM (stream-ordered allocation)
-    HIP_TRY(hipMallocAsync(&scratch, (size_t)n_q * k * 12, stream));
-    a.scratch_s = (uint64_t*)scratch;
-    a.scratch_id = (uint32_t*)((char*)scratch + (size_t)n_q * k * 8);
-  } else if (index->split_chunks && !lm) {
-    // Splitting pays (1) when the batch cannot fill the machine by itself: every query above 2 MiB of postings is cut
-    // into 1 MiB parts; (2) for the outliers of a big batch, which would otherwise be its tail: one wavefront streams
-    // ~1/3000 of the machine's rate, so a query holding more than 2x the expected volume and more than ~1/30000 of the
-    // batch's is cut into parts of a quarter of that.  A big batch of equally heavy queries is left alone.
-    const double batch_chunks = (double)n_q * index->est_query_chunks;
-    double smin = 2.0 * index->split_chunks;
-    if (n_q > 4096u) smin = std::max(smin, std::max(2.0 * index->est_query_chunks, batch_chunks / 30000.0));
-    a.split_min = (uint32_t)std::min(smin, 4.0e9);
-    a.split_chunks = std::max<uint32_t>(index->split_chunks, a.split_min / 4u);
-    // an index whose queries do not come near the threshold (4x the expected volume) pays nothing for the machinery
-    if (4.0 * index->est_query_chunks < (double)a.split_min) a.split_min = 0;
-  }
-  if (a.split_min) {
-    const size_t per_slot = (size_t)SG_MAX_PARTS * k * 12;
-    a.slot_cap = (uint32_t)std::min<size_t>(n_q, ((size_t)1 << 30) / per_slot);
-    a.item_cap = std::min<uint32_t>(std::max<uint32_t>(n_q * 4u, 4096u), 262144u);
-    const size_t o_items = 64, o_slot = o_items + (size_t)a.item_cap * 16, o_pn = o_slot + (size_t)a.slot_cap * 8,
-                 o_ps = (o_pn + (size_t)a.slot_cap * SG_MAX_PARTS * 4 + 15) & ~(size_t)15,
-                 o_pid = o_ps + (size_t)a.slot_cap * SG_MAX_PARTS * k * 8, total = o_pid + (size_t)a.slot_cap * SG_MAX_PARTS * k * 4;
-    HIP_TRY(hipMallocAsync(&scratch, total, stream));
-    HIP_TRY(hipMemsetAsync(scratch, 0, o_items, stream));    // queue control words
-    char* base = (char*)scratch;
-    a.split_ctl = (uint32_t*)base;
-    a.items = (uint32_t*)(base + o_items);
-    a.slot_ctl = (uint32_t*)(base + o_slot);
-    a.part_n = (uint32_t*)(base + o_pn);
-    a.part_s = (uint64_t*)(base + o_ps);
-    a.part_id = (uint32_t*)(base + o_pid);
-  }
-  if (lm) hipLaunchKernelGGL(sg_lm_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
-  else hipLaunchKernelGGL(sg_search_kernel, dim3(n_q), dim3(64), lds_bytes(a.log2_cnt), stream, a);
-  HIP_TRY(hipGetLastError());
-  if (a.split_ctl) {     // the queued parts of split queries: persistent wavefronts, which leave at once if there are none
-    // the parts of a small batch are long streams on a machine they cannot fill anyway: they get 4x the counters (fewer
-    // docID-range passes; the launch has its own LDS size).  q=2: one query 0.57 -> 0.43 ms, 256 queries +30 %.
-    a.log2_cnt = std::min<uint32_t>(index->log2_cnt + (n_q <= 4096u ? index->parts_cnt_bonus : 0u), 14u);
-    hipLaunchKernelGGL(sg_parts_kernel, dim3(index->parts_grid), dim3(64), lds_bytes(a.log2_cnt), stream, a);
-    HIP_TRY(hipGetLastError());
-  }
-  if (scratch) HIP_TRY(hipFreeAsync(scratch, stream));
-  return SG_OK;
-}
-
-}  // namespace
-
-#include "index_build.inc"
-
-extern "C" {
-
-const char* sg_last_error(void) { return g_err.c_str(); }
-
-static int build_any(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments, int device,
-                     sg_index** out) {
-  if (!out || !offs || (!utf8 && n_docs && offs[n_docs])) { set_error("null argument"); return SG_E_INVALID; }   // (all-empty documents need no bytes)
-  auto* ix = new (std::nothrow) sg_index();
-  if (!ix) return SG_E_NOMEM;
-  ix->host.min_segments = min_segments;
-  std::string err;
-  int rc;
-  try {
-    if (device < 0) {
-      rc = build_host_index(utf8, offs, n_docs, desc, ix->host, err);
-      if (rc) set_error(err);
-    } else {
-      rc = init_description(desc, ix->host, err);
-      if (rc) set_error(err);
-      else rc = build_on_device(ix, utf8, offs, n_docs, device);
-    }
-  } catch (const std::bad_alloc&) {
-    set_error("out of host memory"); rc = SG_E_NOMEM;
-  }
-  for (void* p : ix->allocs) (void)hipFree(p);   // the description tables of a device build; sg_index_upload makes its own
-  ix->allocs.clear();
-  ix->device_bytes = 0;
-  if (!rc && (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX)) {
-    set_error("wrap strings longer than 8 runes"); rc = SG_E_UNSUPPORTED;
-  }
-  if (rc) { delete ix; return rc; }
-  *out = ix;
-  return SG_OK;
-}
-
-int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, sg_index** out) {
-  return build_any(utf8, offs, n_docs, desc, 0, -1, out);
-}
-
-int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device, sg_index** out) {
-  if (device < 0) { set_error("bad device"); return SG_E_INVALID; }
-  return build_any(utf8, offs, n_docs, desc, 0, device, out);
-}
-
-int sg_index_build_ex(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, uint32_t min_segments, int device,
-                      sg_index** out) {
-  return build_any(utf8, offs, n_docs, desc, min_segments, device, out);
-}
-
-int sg_index_digest(const sg_index* ix, uint64_t out[4]) {
-  if (!ix || !out) { set_error("null argument"); return SG_E_INVALID; }
-  const HostIndex& h = ix->host;
-  auto fold = [](const void* p, size_t bytes) {
-    uint64_t acc = 0x9E3779B97F4A7C15ull ^ bytes;
-    const uint8_t* b = (const uint8_t*)p;
-    size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); acc = mix64(acc ^ w); }
-    for (; i < bytes; i++) acc = mix64(acc ^ b[i]);
-    return acc;
-  };
-  out[0] = fold(h.postings.data(), h.postings.size() * 4);
-  out[1] = fold(h.seg_off.data(), h.seg_off.size() * 4);
-  out[2] = fold(h.list_len.data(), h.list_len.size() * 4);
-  out[3] = fold(h.term_key.data(), h.term_key.size() * 8) ^ mix64(h.dups.size() * 4 + h.n_segments) ^
-           fold(h.dups.data(), h.dups.size() * sizeof(DupEntry));
-  return SG_OK;
-}
-
-int sg_index_load_reference(const char* hd_path, const char* dl_path, const sg_desc* desc, sg_index** out) {
-  if (!out || !hd_path || !dl_path) { set_error("null argument"); return SG_E_INVALID; }
-  auto* ix = new (std::nothrow) sg_index();
-  if (!ix) return SG_E_NOMEM;
-  std::string err;
-  int rc;
-  try {
-    rc = load_reference_index(hd_path, dl_path, desc, ix->host, err);
-  } catch (const std::bad_alloc&) { rc = SG_E_NOMEM; err = "out of host memory"; }
-  if (rc) { set_error(err); delete ix; return rc; }
-  if (ix->host.wrap0.size() > SG_WRAP_MAX || ix->host.wrap1.size() > SG_WRAP_MAX) {
-    set_error("wrap strings longer than 8 runes"); delete ix; return SG_E_UNSUPPORTED;
-  }
-  *out = ix;
-  return SG_OK;
-}
-
-int sg_index_upload(sg_index* ix, int device) {
-  if (!ix) { set_error("null index"); return SG_E_INVALID; }
-  if (ix->uploaded) return SG_OK;
-  HIP_TRY(hipSetDevice(device));
-  const HostIndex& h = ix->host;
-  DeviceIndex& d = ix->dix;
-  int rc;
-  if ((rc = to_device(ix, h.postings.data(), h.postings.size(), &d.postings))) return rc;
-  {  // one sample per 64 postings of the store: lets a docID-range pass cut its lists without probing them
-    const size_t n_chunks = h.postings.size() / 4;
-    std::vector<uint32_t> cs(n_chunks / 16 + 2, 0xFFFFFFFFu);
-    for (size_t g = 0; g * 16 < n_chunks; g++) cs[g] = h.postings[g * 64];
-    if ((rc = to_device(ix, cs.data(), cs.size(), &d.cut_sample))) return rc;
-  }
-  if ((rc = to_device(ix, h.seg_off.data(), h.seg_off.size(), &d.seg_off))) return rc;
-  if ((rc = to_device(ix, h.slots.data(), h.slots.size(), &d.slots))) return rc;
-  if ((rc = upload_description(ix, d))) return rc;
-  if (!h.dups.empty()) {   // documents that repeat a term: side tables for the secondary-entry path
-    const uint32_t S32 = h.n_segments;
-    std::vector<uint32_t> dts, ddoc, dmult, ddocs, ets, ecnt;
-    for (const auto& e : h.dups) {
-      const uint32_t ts = e.term * S32 + e.segment;
-      dts.push_back(ts); ddoc.push_back(e.doc); dmult.push_back(e.mult); ddocs.push_back(e.doc);
-      if (!ets.empty() && ets.back() == ts) ecnt.back() += e.mult - 1; else { ets.push_back(ts); ecnt.push_back(e.mult - 1); }
-    }
-    std::sort(ddocs.begin(), ddocs.end());
-    ddocs.erase(std::unique(ddocs.begin(), ddocs.end()), ddocs.end());
-    if ((rc = to_device(ix, dts.data(), dts.size(), &d.dup_ts))) return rc;
-    if ((rc = to_device(ix, ddoc.data(), ddoc.size(), &d.dup_doc))) return rc;
-    if ((rc = to_device(ix, dmult.data(), dmult.size(), &d.dup_mult))) return rc;
-    if ((rc = to_device(ix, ddocs.data(), ddocs.size(), &d.dup_docs))) return rc;
-    std::vector<uint32_t> dbits((size_t)(h.n_docs + 31) / 32 + 1, 0u);
-    for (uint32_t dd : ddocs) dbits[dd >> 5] |= 1u << (dd & 31u);
-    if ((rc = to_device(ix, dbits.data(), dbits.size(), &d.dup_bits))) return rc;
-    if ((rc = to_device(ix, ets.data(), ets.size(), &d.extra_ts))) return rc;
-    if ((rc = to_device(ix, ecnt.data(), ecnt.size(), &d.extra_cnt))) return rc;
-    if ((rc = to_device(ix, h.list_len.data(), h.list_len.size(), &d.list_len))) return rc;
-    d.n_dups = (uint32_t)dts.size(); d.n_dup_docs = (uint32_t)ddocs.size(); d.n_extra = (uint32_t)ets.size();
-  }
-  d.slot_mask = (uint32_t)h.slots.size() - 1;
-  d.S = h.n_segments;
-  d.n_docs = (uint32_t)h.n_docs;
-  d.n_terms = (uint32_t)h.term_key.size();
-  ix->device = device;
-  const char* env = getenv("SG_LOG2_CNT");   // tuning knob: LDS counter words per wavefront (default 1024)
-  if (env) { int v = atoi(env); if (v >= 9 && v <= 14) ix->log2_cnt = (uint32_t)v; }
-  env = getenv("SG_T_FLOOR");                 // tuning knob: lowest flag threshold list skipping may leave (default 10)
-  if (env) { int v = atoi(env); if (v >= 2 && v <= 64) ix->t_floor = v; }
-  {  // a query term is a dictionary term drawn by occurrence: E[list length] = sum len^2 / sum len (size-biased)
-    const size_t S = h.n_segments, nt = h.term_key.size();
-    double s1 = 0, s2 = 0;
-    for (size_t t = 0; t < nt; t++) {
-      const double len = (double)(h.seg_off[t * (S + 1) + S] - h.seg_off[t * (S + 1)]);
-      s1 += len; s2 += len * len;
-      ix->max_term_chunks = std::max(ix->max_term_chunks, len);
-    }
-    const double terms_per_doc = h.n_docs ? (double)h.n_postings_raw / (double)h.n_docs : 0.0;
-    ix->est_query_chunks = s1 > 0 ? terms_per_doc * s2 / s1 : 0.0;
-    ix->terms_per_doc = terms_per_doc;
-    // long-list indexes (q = 2, skewed symbols: megabytes of postings per query) run mostly docID-range passes: twice
-    // the counter words halve the passes and more than pay for the lost occupancy (skewed 10M: +10 %, q=2: +3 %)
-    if (!getenv("SG_LOG2_CNT") && ix->est_query_chunks > 131072.0) ix->log2_cnt = 12;
-    if (getenv("SG_VERBOSE")) fprintf(stderr, "[suggest_hip] terms/doc %.2f, expected query volume %.0f chunks, longest term %.0f chunks\n", terms_per_doc, ix->est_query_chunks, ix->max_term_chunks);
-  }
-  env = getenv("SG_SPLIT_CHUNKS");            // tuning knob: fewest 16-byte chunks per part of a split query (default 65536; 0 = off)
-  if (env && *env) ix->split_chunks = (uint32_t)std::max(0, atoi(env));
-  env = getenv("SG_FILTER_LEVEL");            // tuning knob: 0..3 = chance of a false bucket 3e-5 .. 1e-6 (default 2)
-  if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->filter_level = (uint32_t)v; }
-  env = getenv("SG_PARTS_CNT_BONUS");         // tuning knob: log2 of how much larger the parts launch's counter array is
-  if (env) { int v = atoi(env); if (v >= 0 && v <= 3) ix->parts_cnt_bonus = (uint32_t)v; }
-  // (the attribute belongs to the function, not to the index: always the largest size any index may ask for)
-  HIP_TRY(hipFuncSetAttribute((const void*)sg_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(14)));
-  HIP_TRY(hipFuncSetAttribute((const void*)sg_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(14)));
-  {  // per-launch scratch comes from the device's stream-ordered pool: keep freed blocks instead of returning them
-    hipMemPool_t pool;
-    uint64_t keep = ~0ull;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-  }
-  HIP_TRY(hipFuncSetAttribute((const void*)sg_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes(14)));
-  ix->uploaded = true;
-  return SG_OK;
-}
-
-void sg_index_retain(sg_index* ix) { if (ix) ix->refs.fetch_add(1); }
-void sg_index_release(sg_index* ix) {
-  if (!ix) return;
-  if (ix->refs.fetch_sub(1) != 1) return;
-  if (ix->uploaded) { (void)hipSetDevice(ix->device); for (void* p : ix->allocs) (void)hipFree(p); }
-  delete ix;
-}
-
-int sg_suggest_batch_device(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, int metric,
-                            double similarity, uint32_t k, void* d_ids, void* d_scores, void* d_counts, void* stream) {
-  int rc = check_search_args(index, k, true, similarity, metric);
-  if (rc) return rc;
-  return launch(index, d_q, d_offs, n_q, metric, similarity, k, 0, d_ids, d_scores, d_counts, (hipStream_t)stream);
-}
-
-int sg_autocomplete_batch_device(sg_index* index, const void* d_q, const void* d_offs, uint32_t n_q, uint32_t limit,
-                                 void* d_ids, void* d_counts, void* stream) {
-  int rc = check_search_args(index, limit, false, 0, 0);
-  if (rc) return rc;
-  return launch(index, d_q, d_offs, n_q, 0, 0, limit, 1, d_ids, nullptr, d_counts, (hipStream_t)stream);
-}
-
-// Per-thread, per-device context of the host-buffer entry points: a stream and a pinned staging buffer that are made once
-// and reused (a request-per-call service pays ~60 us per call instead of ~450 us of hipMalloc / hipFree / stream
-// creation).  Contexts live as long as their thread.
-struct HostCtx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  void* pinned = nullptr;
-  size_t pinned_cap = 0;
-};
-static thread_local std::vector<HostCtx> t_ctx;
-static const size_t kPinnedMax = (size_t)64 << 20;   // bigger batches copy straight from / to the caller's (pageable) buffers
-
-static int host_ctx(int device, size_t want_pinned, HostCtx** out) {
-  HostCtx* c = nullptr;
-  for (auto& x : t_ctx) if (x.device == device) c = &x;
-  if (!c) {
-    t_ctx.push_back(HostCtx{});
-    c = &t_ctx.back();
-    c->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  }
-  if (want_pinned > c->pinned_cap && want_pinned <= kPinnedMax) {
-    if (c->pinned) (void)hipHostFree(c->pinned);
-    c->pinned = nullptr; c->pinned_cap = 0;
-    size_t cap = (size_t)1 << 16;
-    while (cap < want_pinned) cap <<= 1;
-    HIP_TRY(hipHostMalloc(&c->pinned, cap, hipHostMallocDefault));
-    c->pinned_cap = cap;
-  }
-  *out = c;
-  return SG_OK;
-}
-
-static int run_host(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric, double sim,
-                    uint32_t k, int autocomplete, uint32_t* ids, double* scores, uint32_t* counts) {
-  if (n_q == 0) return SG_OK;
-  if (!q && offs[n_q]) { set_error("null query buffer"); return SG_E_INVALID; }
-  HIP_TRY(hipSetDevice(index->device));
-  // one device block: [scores | ids | counts] (results, one copy back) then [offsets | queries] (inputs, one copy in)
-  const size_t qbytes = (size_t)offs[n_q];
-  const size_t sc_bytes = autocomplete ? 0 : (size_t)n_q * k * 8, id_bytes = (size_t)n_q * k * 4, cnt_bytes = (size_t)n_q * 4;
-  const size_t out_bytes = sc_bytes + id_bytes + cnt_bytes, off_bytes = (size_t)(n_q + 1) * 8;
-  const size_t o_in = (out_bytes + 15) & ~(size_t)15, in_bytes = off_bytes + qbytes, total = o_in + in_bytes + 16;
-  HostCtx* ctx;
-  int rc = host_ctx(index->device, std::max(in_bytes, out_bytes), &ctx);
-  if (rc) return rc;
-  const bool staged = std::max(in_bytes, out_bytes) <= ctx->pinned_cap;
-  hipStream_t st = ctx->stream;
-  char* dev = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&dev, total, st));
-#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); (void)hipFreeAsync(dev, st); (void)hipStreamSynchronize(st); return SG_E_HIP; } } while (0)
-  char* d_sc = dev; char* d_ids = dev + sc_bytes; char* d_cnt = d_ids + id_bytes; char* d_offs = dev + o_in; char* d_q = d_offs + off_bytes;
-  if (staged) {
-    memcpy(ctx->pinned, offs, off_bytes);
-    if (qbytes) memcpy((char*)ctx->pinned + off_bytes, q, qbytes);
-    TRY2(hipMemcpyAsync(d_offs, ctx->pinned, in_bytes, hipMemcpyHostToDevice, st));
-  } else {
-    TRY2(hipMemcpyAsync(d_offs, offs, off_bytes, hipMemcpyHostToDevice, st));
-    if (qbytes) TRY2(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, st));
-  }
-  TRY2(hipMemsetAsync(dev, 0, sc_bytes + id_bytes, st));       // rows of queries with fewer than k results stay zero
-  rc = launch(index, d_q, d_offs, n_q, metric, sim, k, autocomplete, d_ids, autocomplete ? nullptr : d_sc, d_cnt, st);
-  if (rc) { (void)hipFreeAsync(dev, st); (void)hipStreamSynchronize(st); return rc; }
-  if (staged) {
-    TRY2(hipMemcpyAsync(ctx->pinned, dev, out_bytes, hipMemcpyDeviceToHost, st));
-    TRY2(hipFreeAsync(dev, st));
-    TRY2(hipStreamSynchronize(st));
-    const char* h = (const char*)ctx->pinned;
-    if (!autocomplete) memcpy(scores, h, sc_bytes);
-    memcpy(ids, h + sc_bytes, id_bytes);
-    memcpy(counts, h + sc_bytes + id_bytes, cnt_bytes);
-  } else {
-    if (!autocomplete) TRY2(hipMemcpyAsync(scores, d_sc, sc_bytes, hipMemcpyDeviceToHost, st));
-    TRY2(hipMemcpyAsync(ids, d_ids, id_bytes, hipMemcpyDeviceToHost, st));
-    TRY2(hipMemcpyAsync(counts, d_cnt, cnt_bytes, hipMemcpyDeviceToHost, st));
-    TRY2(hipFreeAsync(dev, st));
-    TRY2(hipStreamSynchronize(st));
-  }
-#undef TRY2
-  return SG_OK;
-}
-
-int sg_suggest_batch(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric, double similarity,
-                     uint32_t k, uint32_t* ids, double* scores, uint32_t* counts) {
-  int rc = check_search_args(index, k, true, similarity, metric);
-  if (rc) return rc;
-  if (!offs || !ids || !scores || !counts) { set_error("null argument"); return SG_E_INVALID; }
-  return run_host(index, q, offs, n_q, metric, similarity, k, 0, ids, scores, counts);
-}
-
-int sg_autocomplete_batch(sg_index* index, const uint8_t* q, const uint64_t* offs, uint32_t n_q, uint32_t limit,
-                          uint32_t* ids, uint32_t* counts) {
-  int rc = check_search_args(index, limit, false, 0, 0);
-  if (rc) return rc;
-  if (!offs || !ids || !counts) { set_error("null argument"); return SG_E_INVALID; }
-  return run_host(index, q, offs, n_q, 0, 0, limit, 1, ids, nullptr, counts);
-}
-
-
-// ------------------------------------------------------------------------------------------
-// language model + SpellChecker.Predict
-// ------------------------------------------------------------------------------------------
-int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const char* const* alphabet,
-                      uint32_t n_alphabet, sg_lm** out) {
-  if (!dir || !out) { set_error("null argument"); return SG_E_INVALID; }
-  auto* lm = new (std::nothrow) sg_lm();
-  if (!lm) return SG_E_NOMEM;
-  std::vector<std::string> alpha;
-  for (uint32_t i = 0; i < n_alphabet; i++) alpha.emplace_back(alphabet[i]);
-  std::string err;
-  int rc;
-  try {
-    rc = lm_load_google(dir, order, start_symbol, end_symbol, alpha, lm->host, err);
-  } catch (const std::exception& e) {
-    err = e.what(); rc = SG_E_INVALID;
-  }
-  if (rc) { set_error(err); delete lm; return rc; }
-  *out = lm;
-  return SG_OK;
-}
-
-int sg_lm_build_google(const uint8_t* text, uint64_t len, uint32_t order, const char* start_symbol, const char* end_symbol,
-                       const char* const* alphabet, uint32_t n_alphabet, const char* const* separators, uint32_t n_separators,
-                       const char* out_dir) {
-  if ((!text && len) || !start_symbol || !end_symbol || !out_dir) { set_error("null argument"); return SG_E_INVALID; }
-  std::vector<std::string> alpha, seps;
-  for (uint32_t i = 0; i < n_alphabet; i++) alpha.emplace_back(alphabet[i]);
-  for (uint32_t i = 0; i < n_separators; i++) seps.emplace_back(separators[i]);
-  std::string err;
-  const int rc = lm_build_google_files(text, (size_t)len, order, start_symbol, end_symbol, alpha, seps, out_dir, err);
-  if (rc) set_error(err);
-  return rc;
-}
-
-void sg_lm_retain(sg_lm* lm) { if (lm) lm->refs.fetch_add(1); }
-void sg_lm_release(sg_lm* lm) {
-  if (!lm || lm->refs.fetch_sub(1) != 1) return;
-  if (lm->d_values) { (void)hipSetDevice(lm->device); (void)hipFree(lm->d_values); }
-  delete lm;
-}
-uint32_t sg_lm_num_words(const sg_lm* lm) { return lm ? (uint32_t)lm->host.words.size() : 0u; }
-int sg_lm_word(const sg_lm* lm, uint32_t id, char* out, uint32_t cap) {
-  if (!lm || id >= lm->host.words.size()) { set_error("no such word id"); return SG_E_INVALID; }
-  const std::string& w = lm->host.words[id];
-  if (w.size() <= cap) memcpy(out, w.data(), w.size());
-  return (int)w.size();
-}
-uint32_t sg_lm_word_id(const sg_lm* lm, const uint8_t* word, uint32_t len) {
-  return lm ? lm_word_id(lm->host, std::string((const char*)word, len)) : kUnknownWord;
-}
-double sg_lm_score(const sg_lm* lm, const uint32_t* ids, uint32_t n) { return lm_model_score(lm->host, ids, n); }
-double sg_lm_score_word_ids(const sg_lm* lm, const uint32_t* ids, uint32_t n) { return lm_score_word_ids(lm->host, ids, n); }
-int sg_lm_next_score(const sg_lm* lm, const uint32_t* context, uint32_t n, uint32_t word, int model_level, double* score) {
-  const LmNext nx = model_level ? lm_model_next(lm->host, context, n) : lm_next(lm->host, context, n);
-  if (score) *score = nx.status ? 0.0 : lm_next_score(lm->host, nx, word);
-  return nx.status;
-}
-int sg_lm_tokenize(const sg_lm* lm, const uint8_t* text, uint32_t len, char* out, uint32_t cap) {
-  std::vector<std::string> toks;
-  lm_tokenize(lm->host, text, len, toks);
-  std::string joined;
-  for (size_t i = 0; i < toks.size(); i++) { if (i) joined.push_back('\n'); joined += toks[i]; }
-  if (joined.size() < cap) { memcpy(out, joined.data(), joined.size()); out[joined.size()] = 0; }
-  return (int)toks.size();
-}
-
-int sg_spell_index_build(const sg_lm* lm, const sg_desc* desc, int device, sg_index** out) {
-  if (!lm || !out) { set_error("null argument"); return SG_E_INVALID; }
-  std::string blob;
-  std::vector<uint64_t> offs(1, 0);
-  for (const auto& w : lm->host.words) { blob += w; offs.push_back(blob.size()); }   // docID = word id
-  int rc = sg_index_build((const uint8_t*)blob.data(), offs.data(), (uint32_t)lm->host.words.size(), desc, out);
-  if (rc) return rc;
-  rc = sg_index_upload(*out, device);
-  if (rc) { sg_index_release(*out); *out = nullptr; }
-  return rc;
-}
-
-static int lm_upload(sg_lm* lm, int device) {
-  std::lock_guard<std::mutex> lock(lm->mu);
-  if (lm->d_values) {
-    if (lm->device != device) { set_error("language model already resident on another device"); return SG_E_INVALID; }
-    return SG_OK;
-  }
-  std::vector<uint64_t> flat;
-  for (const LmLevel& lv : lm->host.level) {
-    lm->level_base.push_back((uint32_t)flat.size());
-    for (size_t i = 0; i < lv.word.size(); i++) flat.push_back(((uint64_t)lv.word[i] << 32) | lv.count[i]);
-  }
-  if (flat.size() >= 0xFFFFFFF0ull) { set_error("language model too large"); return SG_E_UNSUPPORTED; }
-  HIP_TRY(hipSetDevice(device));
-  void* p = nullptr;
-  HIP_TRY(hipMalloc(&p, std::max<size_t>(flat.size() * 8, 16)));
-  if (!flat.empty()) HIP_TRY(hipMemcpy(p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice));
-  lm->d_values = (uint64_t*)p;
-  lm->device = device;
-  return SG_OK;
-}
-
-// SpellChecker.Predict (pkg/spellchecker/spellchecker.go:40-92) for a batch.  Host: word tokeniser, word ids, Next
-// (a handful of binary searches per query).  GPU: Autocomplete with the LM collector for every query in one launch
-// (top-k by ScoreNext = by the continuation count), then the Cosine fuzzy search for the queries that got fewer than
-// topK.  Host again: merge, stable sort by ScoreNext, candidates[:topK+1] (sic).
-int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t top_k,
-                           double similarity, uint32_t* out_ids, uint32_t* out_counts) {
-  int rc = check_search_args(index, top_k, true, similarity, SG_COSINE);
-  if (rc) return rc;
-  if (!lm || !q_offs || !out_ids || !out_counts) { set_error("null argument"); return SG_E_INVALID; }
-  if (top_k + 1 > SG_MAX_TOPK) { set_error("topK above SG_MAX_TOPK - 1"); return SG_E_INVALID; }
-  if (n_q == 0) return SG_OK;
-  if ((rc = lm_upload(lm, index->device))) return rc;
-  const HostLM& h = lm->host;
-  const size_t row = (size_t)top_k + 1;
-
-  // ---- host: last word + the continuations of its context ----
-  std::vector<LmNext> next(n_q);
-  std::vector<uint8_t> has_word(n_q, 0);
-  std::vector<std::string> last_word(n_q);
-  std::vector<uint32_t> lm_from(n_q, 0), lm_to(n_q, 0);
-  auto parallel_for = [&](const std::function<void(uint32_t, uint32_t)>& body) {   // host steps are per query: spread them
-    const uint32_t n_thr = std::max(1u, std::min(std::min(std::thread::hardware_concurrency(), 32u), n_q / 2048u));
-    if (n_thr <= 1) { body(0, n_q); return; }
-    std::vector<std::thread> pool;
-    for (uint32_t t = 0; t < n_thr; t++)
-      pool.emplace_back(body, (uint32_t)((uint64_t)n_q * t / n_thr), (uint32_t)((uint64_t)n_q * (t + 1) / n_thr));
-    for (auto& th : pool) th.join();
-  };
-  parallel_for([&](uint32_t lo, uint32_t hi) {
-    std::vector<std::string> toks;
-    std::vector<uint32_t> ids;
-    for (uint32_t i = lo; i < hi; i++) {
-      out_counts[i] = 0;
-      lm_tokenize(h, q_utf8 + q_offs[i], (size_t)(q_offs[i + 1] - q_offs[i]), toks);
-      next[i].status = 1;
-      if (toks.empty()) continue;
-      has_word[i] = 1;
-      last_word[i] = toks.back();
-      ids.clear();
-      for (size_t t = 0; t + 1 < toks.size(); t++) ids.push_back(lm_word_id(h, toks[t]));
-      if (!ids.empty()) {                                       // spellchecker.go:94-107
-        next[i] = lm_next(h, ids.data(), ids.size());
-        if (next[i].status == 0) { lm_from[i] = lm->level_base[next[i].level] + next[i].from; lm_to[i] = lm->level_base[next[i].level] + next[i].to; }
-      }
-    }
-  });
-  std::string words;
-  std::vector<uint64_t> w_offs(1, 0);
-  for (uint32_t i = 0; i < n_q; i++) { words += last_word[i]; w_offs.push_back(words.size()); }
-
-  // ---- GPU: LM-ranked autocomplete of every last word ----
-  HIP_TRY(hipSetDevice(index->device));
-  HostCtx* ctx;
-  if ((rc = host_ctx(index->device, 0, &ctx))) return rc;
-  hipStream_t st = ctx->stream;
-  std::vector<void*> dev;
-  auto cleanup = [&]() { for (void* p : dev) (void)hipFreeAsync(p, st); (void)hipStreamSynchronize(st); };
-#define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return SG_E_HIP; } } while (0)
-  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMallocAsync(p, std::max<size_t>(bytes, 16), st); if (e == hipSuccess) dev.push_back(*p); return e; };
-  void *dq, *doffs, *dfrom, *dto, *dids, *dcnt;
-  TRY3(dalloc(&dq, words.size())); TRY3(dalloc(&doffs, (size_t)(n_q + 1) * 8)); TRY3(dalloc(&dfrom, (size_t)n_q * 4));
-  TRY3(dalloc(&dto, (size_t)n_q * 4)); TRY3(dalloc(&dids, (size_t)n_q * top_k * 4)); TRY3(dalloc(&dcnt, (size_t)n_q * 4));
-  if (!words.empty()) TRY3(hipMemcpyAsync(dq, words.data(), words.size(), hipMemcpyHostToDevice, st));
-  TRY3(hipMemcpyAsync(doffs, w_offs.data(), (size_t)(n_q + 1) * 8, hipMemcpyHostToDevice, st));
-  TRY3(hipMemcpyAsync(dfrom, lm_from.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, st));
-  TRY3(hipMemcpyAsync(dto, lm_to.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, st));
-  TRY3(hipMemsetAsync(dids, 0, (size_t)n_q * top_k * 4, st));
-  const LmRanges ranges{lm->d_values, (const uint32_t*)dfrom, (const uint32_t*)dto};
-  rc = launch(index, dq, doffs, n_q, 0, 0, top_k, 1, dids, nullptr, dcnt, st, &ranges);
-  if (rc) { cleanup(); return rc; }
-  std::vector<uint32_t> a_ids((size_t)n_q * top_k), a_cnt(n_q);
-  TRY3(hipMemcpyAsync(a_ids.data(), dids, a_ids.size() * 4, hipMemcpyDeviceToHost, st));
-  TRY3(hipMemcpyAsync(a_cnt.data(), dcnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, st));
-  TRY3(hipStreamSynchronize(st));
-
-  // ---- GPU: fuzzy search (Cosine) for the queries whose completion list is short ----
-  std::vector<uint32_t> need;
-  for (uint32_t i = 0; i < n_q; i++) {
-    if (a_cnt[i] == SG_COUNT_TOO_LONG) { out_counts[i] = SG_COUNT_TOO_LONG; continue; }
-    if (has_word[i] && a_cnt[i] < top_k) need.push_back(i);
-  }
-  std::vector<uint32_t> f_ids, f_cnt;
-  if (!need.empty()) {
-    std::string fw;
-    std::vector<uint64_t> f_offs(1, 0);
-    for (uint32_t i : need) { fw.append(words, (size_t)w_offs[i], (size_t)(w_offs[i + 1] - w_offs[i])); f_offs.push_back(fw.size()); }
-    const uint32_t n_f = (uint32_t)need.size();
-    void *fq, *fo, *fi, *fs, *fc;
-    TRY3(dalloc(&fq, fw.size())); TRY3(dalloc(&fo, (size_t)(n_f + 1) * 8)); TRY3(dalloc(&fi, (size_t)n_f * top_k * 4));
-    TRY3(dalloc(&fs, (size_t)n_f * top_k * 8)); TRY3(dalloc(&fc, (size_t)n_f * 4));
-    if (!fw.empty()) TRY3(hipMemcpyAsync(fq, fw.data(), fw.size(), hipMemcpyHostToDevice, st));
-    TRY3(hipMemcpyAsync(fo, f_offs.data(), (size_t)(n_f + 1) * 8, hipMemcpyHostToDevice, st));
-    TRY3(hipMemsetAsync(fi, 0, (size_t)n_f * top_k * 4, st));
-    rc = launch(index, fq, fo, n_f, SG_COSINE, similarity, top_k, 0, fi, fs, fc, st);
-    if (rc) { cleanup(); return rc; }
-    f_ids.resize((size_t)n_f * top_k); f_cnt.resize(n_f);
-    TRY3(hipMemcpyAsync(f_ids.data(), fi, f_ids.size() * 4, hipMemcpyDeviceToHost, st));
-    TRY3(hipMemcpyAsync(f_cnt.data(), fc, (size_t)n_f * 4, hipMemcpyDeviceToHost, st));
-    TRY3(hipStreamSynchronize(st));
-  }
-#undef TRY3
-  cleanup();
-
-  // ---- host: merge, re-rank, truncate ----
-  std::vector<uint32_t> fuzzy_of(n_q, 0xFFFFFFFFu);
-  for (size_t j = 0; j < need.size(); j++) fuzzy_of[need[j]] = (uint32_t)j;
-  parallel_for([&](uint32_t lo, uint32_t hi) {
-    std::vector<uint32_t> cands;
-    for (uint32_t i = lo; i < hi; i++) {
-      if (out_counts[i] == SG_COUNT_TOO_LONG || !has_word[i]) continue;
-      if (next[i].status == 2) { out_counts[i] = SG_COUNT_LM_ERROR; continue; }
-      cands.assign(a_ids.begin() + (size_t)i * top_k, a_ids.begin() + (size_t)i * top_k + a_cnt[i]);
-      if (fuzzy_of[i] != 0xFFFFFFFFu) {
-        const uint32_t j = fuzzy_of[i], c = f_cnt[j];
-        if (c >= SG_COUNT_TOO_LONG) { out_counts[i] = c; continue; }     // the reference panics / dead-locks here (suggester.go:62)
-        for (uint32_t x = 0; x < c; x++) {                                 // merge — spellchecker.go:133-150
-          const uint32_t y = f_ids[(size_t)j * top_k + x];
-          if (std::find(cands.begin(), cands.end(), y) == cands.end()) cands.push_back(y);
-        }
-      }
-      if (next[i].status == 0)                                             // sort.SliceStable by ScoreNext desc (monotone in the count)
-        std::stable_sort(cands.begin(), cands.end(), [&](uint32_t x, uint32_t y) { return lm_next_count(h, next[i], x) > lm_next_count(h, next[i], y); });
-      if (top_k < cands.size()) cands.resize(row);                         // candidates[:topK+1] (sic)
-      out_counts[i] = (uint32_t)cands.size();
-      std::copy(cands.begin(), cands.end(), out_ids + (size_t)i * row);
-    }
-  });
-  return SG_OK;
-}
-
-#ifdef SG_PHASE_TIMING
-void sg_debug_set_prof(void* device_u64x8) { g_prof_buf = device_u64x8; }
-#endif
-
-int sg_index_stats(const sg_index* ix, sg_stats* out) {
-  if (!ix || !out) { set_error("null argument"); return SG_E_INVALID; }
-  const HostIndex& h = ix->host;
-  out->n_docs = h.n_docs; out->n_segments = h.n_segments; out->n_terms = h.term_key.size();
-  out->n_lists = h.n_lists; out->n_postings = h.n_postings; out->n_postings_raw = h.n_postings_raw;
-  out->posting_bytes = h.postings.size() * 4;
-  out->table_bytes = h.seg_off.size() * 4 + h.slots.size() * sizeof(TermSlot);
-  out->device_bytes = ix->device_bytes;
-  return SG_OK;
-}
-
-int sg_tokenize(const sg_index* ix, const uint8_t* text, uint32_t len, int autocomplete, uint64_t* out_keys, uint32_t cap) {
-  if (!ix) { set_error("null index"); return SG_E_INVALID; }
-  std::vector<uint64_t> keys;
-  if (!tokenize_keys(ix->host, text, len, autocomplete != 0, keys)) { set_error("term exceeds the 8-symbol key"); return SG_E_UNSUPPORTED; }
-  for (size_t i = 0; i < keys.size() && i < cap; i++) out_keys[i] = keys[i];
-  return (int)keys.size();
-}
-
-int sg_term_string(const sg_index* ix, uint64_t key, char* out, uint32_t cap) {
-  if (!ix) { set_error("null index"); return SG_E_INVALID; }
-  std::string s;
-  for (int i = 0; i < 8; i++) {
-    uint32_t id = (key >> (8 * i)) & 0xFF;
-    if (!id) break;
-    if (id >= ix->host.sym.sym_rune.size()) { set_error("bad symbol id in key"); return SG_E_INVALID; }
-    uint32_t r = ix->host.sym.sym_rune[id];
-    if (r < 0x80) s.push_back((char)r);
-    else if (r < 0x800) { s.push_back((char)(0xC0 | (r >> 6))); s.push_back((char)(0x80 | (r & 0x3F))); }
-    else if (r < 0x10000) { s.push_back((char)(0xE0 | (r >> 12))); s.push_back((char)(0x80 | ((r >> 6) & 0x3F))); s.push_back((char)(0x80 | (r & 0x3F))); }
-    else { s.push_back((char)(0xF0 | (r >> 18))); s.push_back((char)(0x80 | ((r >> 12) & 0x3F))); s.push_back((char)(0x80 | ((r >> 6) & 0x3F))); s.push_back((char)(0x80 | (r & 0x3F))); }
-  }
-  if (s.size() <= cap) memcpy(out, s.data(), s.size());
-  return (int)s.size();
-}
-
-int64_t sg_index_list(const sg_index* ix, uint32_t segment, uint64_t key, uint32_t* out, uint64_t cap, uint64_t* raw_len) {
-  if (!ix) return -1;
-  const HostIndex& h = ix->host;
-  auto it = h.term_of.find(key);
-  if (it == h.term_of.end() || segment >= h.n_segments) return -1;
-  const size_t t = it->second, S = h.n_segments;
-  const uint32_t len = h.list_len[t * S + segment];
-  if (!len) return -1;
-  const uint32_t* p = h.postings.data() + (size_t)h.seg_off[t * (S + 1) + segment] * 4;
-  for (uint32_t i = 0; i < len && i < cap; i++) out[i] = p[i];
-  if (raw_len) {
-    uint64_t raw = len;
-    DupEntry probe{(uint32_t)t, segment, 0, 0};
-    auto lo = std::lower_bound(h.dups.begin(), h.dups.end(), probe, [](const DupEntry& x, const DupEntry& y) {
-      return x.term != y.term ? x.term < y.term : x.segment < y.segment;
-    });
-    for (; lo != h.dups.end() && lo->term == t && lo->segment == segment; ++lo) raw += lo->mult - 1;
-    *raw_len = raw;
-  }
-  return len;
-}
-
-uint64_t sg_index_lists(const sg_index* ix, uint32_t* out_segments, uint64_t* out_keys, uint64_t cap) {
-  if (!ix) return 0;
-  const HostIndex& h = ix->host;
-  const size_t S = h.n_segments;
-  uint64_t n = 0;
-  for (size_t t = 0; t < h.term_key.size(); t++)
-    for (size_t b = 0; b < S; b++)
-      if (h.list_len[t * S + b]) {
-        if (n < cap) { out_segments[n] = (uint32_t)b; out_keys[n] = h.term_key[t]; }
-        n++;
-      }
-  return n;
-}
-
-int sg_suggest_algorithmic_bytes(const sg_index* ix, const uint8_t* q, const uint64_t* offs, uint32_t n_q, int metric,
-                                 double similarity, uint32_t k, uint64_t* out_total) {
-  if (!ix || !offs || !out_total) { set_error("null argument"); return SG_E_INVALID; }
-  const HostIndex& h = ix->host;
-  const int S = (int)h.n_segments;
-  uint64_t total = 0;
-  std::vector<uint64_t> keys;
-  for (uint32_t i = 0; i < n_q; i++) {
-    const size_t len = (size_t)(offs[i + 1] - offs[i]);
-    total += len + 12ull * k;
-    if (!tokenize_keys(h, q + offs[i], len, false, keys) || keys.empty()) continue;
-    const int A = (int)keys.size();
-    int b_min = metric_min_y(metric, similarity, A), b_max = metric_max_y(metric, similarity, A);
-    if (b_max >= S) b_max = S - 1;
-    for (int b = std::max(b_min, 0); b <= b_max; b++) {
-      const int T = metric_threshold(metric, similarity, A, b);
-      if (T == 0 || T > b || T > A) continue;
-      for (uint64_t key : keys) {
-        auto it = h.term_of.find(key);
-        if (it != h.term_of.end()) total += 4ull * h.list_len[(size_t)it->second * S + b];
-      }
-    }
-  }
-  *out_total = total;
-  return SG_OK;
-}
-
-}  // extern "C"
+#include "capi.inc"

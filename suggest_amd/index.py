@@ -3,7 +3,9 @@
 Mirrors suggest.Builder / suggest.NGramIndex (pkg/suggest/ngram_index_builder.go:14-83, ngram_index.go:7-35)
 for the hot path; every call goes through the C ABI of include/suggest_hip.h.
 """
+import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -54,6 +56,7 @@ class NGramIndex:
         d = description or IndexDescription()
         self.description = d
         self.device = None
+        self._hlock = threading.Lock()
         if _handle is not None:
             self._h = _handle
             self.n_docs = self.stats()["n_docs"]
@@ -85,18 +88,55 @@ class NGramIndex:
     def digest(self):
         """64-bit digests of the host CSR arrays (postings, seg_off, list lengths, term keys + repeated-term table)"""
         out = (C.c_uint64 * 4)()
-        _lib.check(_lib.lib().sg_index_digest(self._h, out))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_digest(h, out))
         return tuple(int(x) for x in out)
 
     def upload(self, device=0):
-        _lib.check(_lib.lib().sg_index_upload(self._h, int(device)))
-        self.device = int(device)
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_upload(h, int(device)))
+        if self.device is None:
+            self.device = int(device)
         return self
 
+    def replicate(self, devices):
+        """sg_index_replicate: one host build, a replica in the HBM of every listed GPU."""
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_replicate(h, arr, len(devices)))
+        if self.device is None and devices:
+            self.device = int(devices[0])
+        return self
+
+    def replicas(self):
+        out = (C.c_int * 64)()
+        with self._use() as h:
+            n = _lib.lib().sg_index_replicas(h, out, 64)
+        return [int(out[i]) for i in range(min(n, 64))]
+
+    @contextlib.contextmanager
+    def _use(self):
+        """The handle, retained for the duration of a C call: a concurrent close() (Service re-indexing while queries are in
+        flight — ctypes releases the GIL) only drops its own reference; the index is freed when the last call returns."""
+        L = _lib.lib()
+        with self._hlock:
+            h = self._h
+            if not h:
+                raise ValueError("index is closed")
+            L.sg_index_retain(h)
+        try:
+            yield h
+        finally:
+            L.sg_index_release(h)
+
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().sg_index_release(self._h)
-            self._h = None
+        lock = getattr(self, "_hlock", None)
+        if lock is None:
+            return
+        with lock:
+            h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().sg_index_release(h)
 
     def __del__(self):
         try:
@@ -105,8 +145,9 @@ class NGramIndex:
             pass
 
     # ---- search: host buffers ------------------------------------------------------------
-    def suggest_batch(self, queries=None, metric="jaccard", similarity=0.5, k=10, blob=None, offs=None):
-        """-> (ids[n_q,k] u32, scores[n_q,k] f64, counts[n_q] u32); row i best first."""
+    def suggest_batch(self, queries=None, metric="jaccard", similarity=0.5, k=10, blob=None, offs=None, multi=False):
+        """-> (ids[n_q,k] u32, scores[n_q,k] f64, counts[n_q] u32); row i best first.  multi=True: sg_suggest_batch_multi
+        (the batch sliced over every replica)."""
         if blob is None:
             blob, offs = pack_strings(queries)
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -115,12 +156,14 @@ class NGramIndex:
         ids = np.zeros((n_q, k), dtype=np.uint32)
         sc = np.zeros((n_q, k), dtype=np.float64)
         cnt = np.zeros(n_q, dtype=np.uint32)
-        _lib.check(_lib.lib().sg_suggest_batch(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q,
-                                               resolve(metric).code, float(similarity), int(k), ids.ctypes.data, sc.ctypes.data,
-                                               cnt.ctypes.data))
+        L = _lib.lib()
+        with self._use() as h:
+            _lib.check((L.sg_suggest_batch_multi if multi else L.sg_suggest_batch)(
+                h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code, float(similarity), int(k),
+                ids.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
         return ids, sc, cnt
 
-    def autocomplete_batch(self, queries=None, limit=10, blob=None, offs=None):
+    def autocomplete_batch(self, queries=None, limit=10, blob=None, offs=None, multi=False):
         if blob is None:
             blob, offs = pack_strings(queries)
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -128,23 +171,33 @@ class NGramIndex:
         n_q = len(offs) - 1
         ids = np.zeros((n_q, limit), dtype=np.uint32)
         cnt = np.zeros(n_q, dtype=np.uint32)
-        _lib.check(_lib.lib().sg_autocomplete_batch(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q,
-                                                    int(limit), ids.ctypes.data, cnt.ctypes.data))
+        L = _lib.lib()
+        with self._use() as h:
+            _lib.check((L.sg_autocomplete_batch_multi if multi else L.sg_autocomplete_batch)(
+                h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, int(limit), ids.ctypes.data, cnt.ctypes.data))
         return ids, cnt
 
     # ---- search: device-resident buffers (raw pointers; torch tensors' data_ptr()) ---------
     def suggest_batch_device(self, d_blob, d_offs, n_q, metric, similarity, k, d_ids, d_scores, d_counts, stream=0):
-        _lib.check(_lib.lib().sg_suggest_batch_device(self._h, d_blob, d_offs, int(n_q), resolve(metric).code, float(similarity),
-                                                      int(k), d_ids, d_scores, d_counts, stream))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_suggest_batch_device(h, d_blob, d_offs, int(n_q), resolve(metric).code, float(similarity),
+                                                          int(k), d_ids, d_scores, d_counts, stream))
 
     def autocomplete_batch_device(self, d_blob, d_offs, n_q, limit, d_ids, d_counts, stream=0):
-        _lib.check(_lib.lib().sg_autocomplete_batch_device(self._h, d_blob, d_offs, int(n_q), int(limit), d_ids, d_counts, stream))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_autocomplete_batch_device(h, d_blob, d_offs, int(n_q), int(limit), d_ids, d_counts, stream))
 
     # ---- NGramIndex interface (single query) -----------------------------------------------
     def suggest(self, query, similarity, metric, k):
         """Suggester.Suggest (pkg/suggest/suggester.go:17-20) -> list[(docID, score)] best first."""
-        ids, sc, cnt = self.suggest_batch([query], metric, similarity, k)
-        c = int(cnt[0])
+        q = _enc(query)
+        ids = np.zeros((1, k), dtype=np.uint32)
+        sc = np.zeros((1, k), dtype=np.float64)
+        cnt = C.c_uint32()
+        with self._use() as h:      # one query per call: coalesced with the other callers' (sg_suggest_one)
+            _lib.check(_lib.lib().sg_suggest_one(h, q, len(q), resolve(metric).code, float(similarity), int(k), ids.ctypes.data,
+                                                 sc.ctypes.data, C.addressof(cnt)))
+        c = int(cnt.value)
         if c == _lib.SG_COUNT_REF_PANIC:
             raise RuntimeError("query window is empty: the reference panics here (suggester.go:62, negative channel capacity)")
         if c == _lib.SG_COUNT_REF_DEADLOCK:
@@ -154,8 +207,12 @@ class NGramIndex:
         return [(int(ids[0, i]), float(sc[0, i])) for i in range(c)]
 
     def autocomplete(self, query, limit):
-        ids, cnt = self.autocomplete_batch([query], limit)
-        c = int(cnt[0])
+        q = _enc(query)
+        ids = np.zeros((1, limit), dtype=np.uint32)
+        cnt = C.c_uint32()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_autocomplete_one(h, q, len(q), int(limit), ids.ctypes.data, C.addressof(cnt)))
+        c = int(cnt.value)
         if c == _lib.SG_COUNT_TOO_LONG:
             raise ValueError("query has more than %d n-grams" % _lib.SG_MAX_QUERY_TERMS)
         return [int(ids[0, i]) for i in range(c)]
@@ -163,7 +220,8 @@ class NGramIndex:
     # ---- introspection ---------------------------------------------------------------------
     def stats(self):
         st = _lib.SgStats()
-        _lib.check(_lib.lib().sg_index_stats(self._h, C.byref(st)))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_stats(h, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in st._fields_}
 
     def tokenize_keys(self, text, autocomplete=False):
@@ -203,6 +261,7 @@ class NGramIndex:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         out = C.c_uint64()
-        _lib.check(_lib.lib().sg_suggest_algorithmic_bytes(self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data,
-                                                           len(offs) - 1, resolve(metric).code, float(similarity), int(k), C.byref(out)))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_suggest_algorithmic_bytes(h, blob.ctypes.data if blob.size else None, offs.ctypes.data,
+                                                               len(offs) - 1, resolve(metric).code, float(similarity), int(k), C.byref(out)))
         return int(out.value)

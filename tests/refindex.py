@@ -200,3 +200,123 @@ def read_index(hd_path, dl_path):
     for term, indice, size, pos, length in terms:
         lists[(indice, term)] = (length, decode_list(dl[pos:pos + size], length))
     return indices, lists
+
+
+# ---- writer (tests only): lets a test lay down <name>.hd/.dl in the reference's format for ANY set of lists, e.g. a
+#      roaring-coded list that dropped a document's repeated postings (codec.go:39-51) — the reference's fixtures hold none ----
+def _gob_uint(v):
+    if v < 128:
+        return bytes([v])
+    b = v.to_bytes((v.bit_length() + 7) // 8, "big")
+    return bytes([256 - len(b)]) + b
+
+
+def _gob_int(v):
+    return _gob_uint((~v << 1) | 1 if v < 0 else v << 1)
+
+
+def _enc_varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def encode_vb(postings):
+    out, prev = bytearray(), 0
+    for p in postings:
+        out += _enc_varint(p - prev)
+        prev = p
+    return bytes(out)
+
+
+def encode_skipping(postings, gap=64):
+    out = bytearray()
+    block_first = 0
+    blocks = [postings[i:i + gap] for i in range(0, len(postings), gap)]
+    for bi, blk in enumerate(blocks):
+        body = bytearray()
+        prev = block_first
+        for j, p in enumerate(blk):
+            body += _enc_varint(p - prev)
+            prev = p
+            if j == 0:
+                block_first = p
+        size = len(body) + 2
+        assert size < 0x8000
+        out += struct.pack("<H", size | (0x8000 if bi == len(blocks) - 1 else 0)) + body
+    return bytes(out)
+
+
+def encode_roaring(values):
+    """portable format without run containers (cookie 12346): array containers up to 4096 values, bitmaps above"""
+    cont = {}
+    for v in values:
+        cont.setdefault(v >> 16, []).append(v & 0xFFFF)
+    keys = sorted(cont)
+    head = struct.pack("<II", 12346, len(keys))
+    for k in keys:
+        head += struct.pack("<HH", k, len(cont[k]) - 1)
+    bodies = []
+    for k in keys:
+        vals = cont[k]
+        if len(vals) > 4096:
+            words = [0] * 1024
+            for v in vals:
+                words[v >> 6] |= 1 << (v & 63)
+            bodies.append(struct.pack("<1024Q", *words))
+        else:
+            bodies.append(struct.pack("<%dH" % len(vals), *vals))
+    off = len(head) + 4 * len(keys)
+    offs = b""
+    for b in bodies:
+        offs += struct.pack("<I", off)
+        off += len(b)
+    return head + offs + b"".join(bodies)
+
+
+def write_index(hd_path, dl_path, n_indices, lists, type_prefix_from):
+    """lists: {(indice, term_bytes): (raw_len, stored postings)} as read_index returns them.  The gob type-definition
+    messages are taken verbatim from an existing header file (`type_prefix_from`)."""
+    hd = open(type_prefix_from, "rb").read()
+    g = _Gob(memoryview(hd))
+    while g.i < len(hd):
+        start = g.i
+        n = g.uint()
+        end = g.i + n
+        tid = g.int_()
+        if tid >= 0:
+            type_id, value_start = tid, start
+            break
+        g.i = end
+    dl = bytearray()
+    body = bytearray()
+    body += _gob_int(type_id)
+    body += _gob_uint(1) + _gob_uint(4) + b"v5.1"
+    body += _gob_uint(1) + _gob_uint(n_indices)
+    body += _gob_uint(1) + _gob_uint(len(lists))
+    for (indice, term) in sorted(lists):
+        raw_len, post = lists[(indice, term)]
+        enc = encode_vb(post) if raw_len <= 65 else encode_skipping(post) if raw_len <= 256 else encode_roaring(post)
+        pos = len(dl)
+        dl += enc
+        f = -1
+        rec = bytearray()
+        for idx, val in enumerate((term, indice, len(enc), pos, raw_len)):
+            if idx == 0:
+                if len(val) == 0:
+                    continue
+                rec += _gob_uint(idx - f) + _gob_uint(len(val)) + val
+            else:
+                if val == 0:
+                    continue
+                rec += _gob_uint(idx - f) + _gob_uint(val)
+            f = idx
+        body += rec + b"\x00"
+    body += b"\x00"
+    with open(hd_path, "wb") as f:
+        f.write(hd[:value_start] + _gob_uint(len(body)) + bytes(body))
+    with open(dl_path, "wb") as f:
+        f.write(bytes(dl))
