@@ -153,6 +153,23 @@ typedef struct sg_lm sg_lm;
  * of 1-gm; `alphabet` is the words alphabet of the lm config (pkg/lm/config.go:25-27) used by the query tokenizer. */
 int sg_lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol,
                       const char* const* alphabet, uint32_t n_alphabet, sg_lm** out);
+/* The same files with the word ids the production path gives them: id_order 1 = buildDictionary (pkg/lm/binary.go:101-199),
+ * words ordered by (count desc, word asc) — what `lm build-lm` stores and RetrieveLMFromBinary serves; id_order 0 = the line
+ * order of 1-gm (buildIndexerWithInMemoryDictionary, indexer.go:88-114, used by the reference's tests).  The ids matter:
+ * SpellChecker.Predict breaks ties by docID = word id. */
+int sg_lm_load_google_ex(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol,
+                         const char* const* alphabet, uint32_t n_alphabet, int id_order, sg_lm** out);
+/* RetrieveLMFromBinary (pkg/lm/binary.go:59-98) — what BuildSpellChecker loads (internal/spellchecker/dep/spellchecker.go:13-53):
+ * <name>.lm (nGramModel.Load ngram_model.go:123-160: "0.0.2", order, per level packedArray.Load packed_array.go:118-160)
+ * and the dictionary <name>.cdb (word of every id; pkg/dictionary/cdb_dictionary.go).  The MPH table behind the model in the
+ * file is not read: lookups here are exact. */
+int sg_lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_symbol, const char* end_symbol,
+                      const char* const* alphabet, uint32_t n_alphabet, sg_lm** out);
+/* One level of the model in the reference's packed form (packed_array.go:12-16: containers context<<32|from, values
+ * word<<32|count, total) — what packedArray.Store writes.  Introspection (tests compare with the bytes of a .lm file). */
+int sg_lm_level(const sg_lm* lm, uint32_t level, uint64_t* containers, uint32_t cap_containers, uint32_t* n_containers,
+                uint64_t* values, uint32_t cap_values, uint32_t* n_values, uint32_t* total);
+uint32_t sg_lm_order(const sg_lm* lm);
 /* NGramBuilder.Build over NewSentenceRetriever + googleNGramFormatWriter.Write (pkg/lm/ngram_builder.go:16-64,
  * sentence_retriever.go:17-81, ngram_writer.go:32-76) — what `lm build-lm` does to a corpus: sentences are cut at the
  * runes of `separators`, tokenised, wrapped in start/end symbols and their k-grams (k = 1..order) counted into

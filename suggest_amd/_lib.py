@@ -23,6 +23,7 @@ EXPORTS = [
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch",
     "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one",
+    "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
 
@@ -73,6 +74,11 @@ def lib():
     L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    L.sg_lm_load_google_ex.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp)]
+    L.sg_lm_load_binary.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    L.sg_lm_level.argtypes = [vp, u32, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.sg_lm_order.argtypes = [vp]
+    L.sg_lm_order.restype = u32
     L.sg_lm_build_google.argtypes = [C.c_char_p, u64, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p]
     L.sg_lm_retain.argtypes = [vp]
     L.sg_lm_retain.restype = None

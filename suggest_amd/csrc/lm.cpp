@@ -12,7 +12,9 @@
 // also what the GPU kernel gets (a [from, to) range per query into one flat array of word<<32|count).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 
 #include "sg_internal.h"
@@ -53,7 +55,7 @@ uint32_t lm_word_id(const HostLM& lm, const std::string& token) {
 }
 
 int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const std::vector<std::string>& alphabet,
-                   HostLM& lm, std::string& err) {
+                   int id_order, HostLM& lm, std::string& err) {
   if (order < 1 || order > 8) { err = "nGramOrder should be >= 1"; return SG_E_INVALID; }
   lm.order = order;
   lm.alphabet = alphabet;
@@ -61,10 +63,26 @@ int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, co
     std::ifstream f(std::string(dir) + "/1-gm");
     if (!f) { err = std::string("failed to open ") + dir + "/1-gm"; return SG_E_INVALID; }
     std::string line;
-    while (std::getline(f, line)) {
-      const std::string w = line.substr(0, line.find('\t'));
-      lm.id_of.emplace(w, (uint32_t)lm.words.size());
-      lm.words.push_back(w);
+    if (id_order == 0) {                                       // buildIndexerWithInMemoryDictionary (indexer.go:88-114): line order
+      while (std::getline(f, line)) {
+        const std::string w = line.substr(0, line.find('\t'));
+        lm.id_of.emplace(w, (uint32_t)lm.words.size());
+        lm.words.push_back(w);
+      }
+    } else {                                                   // buildDictionary (binary.go:101-199): ids by (count desc, word asc)
+      std::vector<std::pair<uint32_t, std::string>> items;
+      while (std::getline(f, line)) {
+        const size_t tab = line.find('\t');
+        if (tab == std::string::npos) { err = "strconv.ParseUint: parsing \"\": invalid syntax"; return SG_E_INVALID; }
+        char* endp = nullptr;
+        const unsigned long long c = strtoull(line.c_str() + tab + 1, &endp, 10);
+        if (endp == line.c_str() + tab + 1 || *endp || c > 0xFFFFFFFFull) { err = "strconv.ParseUint: parsing the count of a 1-gm line"; return SG_E_INVALID; }
+        if (tab == 0) continue;                                // an empty word is skipped (binary.go:167-169)
+        items.emplace_back((uint32_t)c, line.substr(0, tab));
+      }
+      std::sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+      items.erase(std::unique(items.begin(), items.end()), items.end());      // an equal item is not inserted twice
+      for (auto& it : items) { lm.id_of.emplace(it.second, (uint32_t)lm.words.size()); lm.words.push_back(it.second); }
     }
   }
   for (uint32_t k = 1; k <= order; k++) {
@@ -108,6 +126,94 @@ int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, co
   lm.start_symbol = lm_word_id(lm, start_symbol ? start_symbol : "");
   lm.end_symbol = lm_word_id(lm, end_symbol ? end_symbol : "");
   return SG_OK;
+}
+
+// dictionary.OpenCDBDictionary (pkg/dictionary/cdb_dictionary.go over alldroll/cdb): D. J. Bernstein's constant database as
+// BuildCDBDictionary writes it (helpers.go:52-100) — key = docID as 4 bytes little endian, value = the word.  Records start at
+// byte 2048 and run to the first hash table.
+static bool read_cdb_words(const char* path, std::vector<std::string>& words, std::string& err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { err = std::string("failed to open cdb dictionary file: ") + path; return false; }
+  std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  auto u32 = [&](size_t o) { return (uint32_t)(uint8_t)d[o] | ((uint32_t)(uint8_t)d[o + 1] << 8) | ((uint32_t)(uint8_t)d[o + 2] << 16) | ((uint32_t)(uint8_t)d[o + 3] << 24); };
+  if (d.size() < 2048) { err = "cdb dictionary is truncated"; return false; }
+  size_t end = d.size();
+  for (int i = 0; i < 256; i++) end = std::min<size_t>(end, u32((size_t)i * 8));
+  std::map<uint32_t, std::string> by_id;
+  for (size_t pos = 2048; pos + 8 <= end;) {
+    const size_t klen = u32(pos), dlen = u32(pos + 4);
+    if (pos + 8 + klen + dlen > end) { err = "cdb dictionary is corrupted"; return false; }
+    if (klen == 4) by_id[u32(pos + 8)] = d.substr(pos + 8 + klen, dlen);
+    pos += 8 + klen + dlen;
+  }
+  words.clear();
+  for (const auto& kv : by_id) { if (kv.first != words.size()) { err = "cdb dictionary has a hole in its ids"; return false; } words.push_back(kv.second); }
+  return true;
+}
+
+// RetrieveLMFromBinary (pkg/lm/binary.go:59-98): <name>.lm = "0.0.2", the order, then per level "containers values total\n" +
+// containers (context << 32 | from, u64 LE) + values (word << 32 | count) (nGramModel.Load ngram_model.go:123-160,
+// packedArray.Load packed_array.go:118-160), then the MPH table — not needed here: the dictionary (<name>.cdb) gives the
+// words in id order and lookups are exact.
+int lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_symbol, const char* end_symbol,
+                   const std::vector<std::string>& alphabet, HostLM& lm, std::string& err) {
+  if (!read_cdb_words(cdb_path, lm.words, err)) return SG_E_INVALID;
+  for (uint32_t i = 0; i < lm.words.size(); i++) lm.id_of.emplace(lm.words[i], i);
+  std::ifstream f(lm_path, std::ios::binary);
+  if (!f) { err = std::string("failed to open the lm binary file: ") + lm_path; return SG_E_INVALID; }
+  const std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  if (d.size() < 6 || d.compare(0, 5, "0.0.2") != 0) { err = "Version mismatch, expected 0.0.2, got " + d.substr(0, std::min<size_t>(5, d.size())); return SG_E_INVALID; }
+  lm.order = (uint8_t)d[5];
+  if (lm.order < 1 || lm.order > 8) { err = "unsupported nGramOrder in the binary model"; return SG_E_INVALID; }
+  lm.alphabet = alphabet;
+  size_t pos = 6;
+  for (uint32_t k = 0; k < lm.order; k++) {
+    const size_t nl = d.find('\n', pos);
+    if (nl == std::string::npos) { err = "unexpected end of the binary model"; return SG_E_INVALID; }
+    unsigned long long cs = 0, vs = 0, total = 0;
+    if (sscanf(d.substr(pos, nl - pos).c_str(), "%llu %llu %llu", &cs, &vs, &total) != 3 || cs % 8 || vs % 8) { err = "malformed packed array header"; return SG_E_INVALID; }
+    pos = nl + 1;
+    if (cs > d.size() - pos || vs > d.size() - pos - cs) { err = "unexpected end of the binary model"; return SG_E_INVALID; }
+    auto u64 = [&](size_t o) { uint64_t v; memcpy(&v, d.data() + o, 8); return v; };
+    const size_t n_c = (size_t)cs / 8, n_v = (size_t)vs / 8;
+    LmLevel lv;
+    lv.total = total;
+    const uint32_t n_parents = parents_of(lm, k);
+    std::vector<uint32_t> start((size_t)n_parents + 2, 0xFFFFFFFFu);
+    start[(size_t)n_parents + 1] = (uint32_t)n_v;
+    uint64_t prev = 0;
+    for (size_t i = 0; i < n_c; i++) {
+      const uint64_t c = u64(pos + i * 8);
+      const uint32_t ctx = (uint32_t)(c >> 32), from = (uint32_t)c;
+      if ((i && c <= prev) || from > n_v) { err = "packed array containers are not ascending"; return SG_E_INVALID; }
+      prev = c;
+      const uint32_t bucket = ctx == kNoContext ? n_parents : ctx;
+      if (bucket > n_parents) { err = "packed array context outside the previous level"; return SG_E_INVALID; }
+      start[bucket] = from;
+    }
+    for (size_t b = (size_t)n_parents + 1; b-- > 0;) if (start[b] == 0xFFFFFFFFu) start[b] = start[b + 1];
+    lv.child_begin = std::move(start);
+    pos += (size_t)cs;
+    lv.word.resize(n_v); lv.count.resize(n_v);
+    for (size_t i = 0; i < n_v; i++) { const uint64_t v = u64(pos + i * 8); lv.word[i] = (uint32_t)(v >> 32); lv.count[i] = (uint32_t)v; }
+    pos += (size_t)vs;
+    lm.level.push_back(std::move(lv));
+  }
+  lm.start_symbol = lm_word_id(lm, start_symbol ? start_symbol : "");
+  lm.end_symbol = lm_word_id(lm, end_symbol ? end_symbol : "");
+  return SG_OK;
+}
+
+// One level in the reference's packed form (packed_array.go:12-16): containers (context << 32 | from) and values
+// (word << 32 | count) — what packedArray.Store would write; lets a test compare a model with the bytes of a .lm file.
+void lm_level_packed(const HostLM& lm, uint32_t level, std::vector<uint64_t>& containers, std::vector<uint64_t>& values, uint32_t* total) {
+  containers.clear(); values.clear();
+  const LmLevel& lv = lm.level[level];
+  const uint32_t n_parents = parents_of(lm, level);
+  for (uint32_t b = 0; b <= n_parents; b++)
+    if (lv.child_begin[b + 1] > lv.child_begin[b]) containers.push_back(((uint64_t)(b == n_parents ? kNoContext : b) << 32) | lv.child_begin[b]);
+  for (size_t i = 0; i < lv.word.size(); i++) values.push_back(((uint64_t)lv.word[i] << 32) | lv.count[i]);
+  *total = (uint32_t)lv.total;
 }
 
 double lm_model_score(const HostLM& lm, const uint32_t* ids, size_t n) {   // NGramModel.Score

@@ -112,7 +112,10 @@ struct LmNext {    // NGramModel.Next: the continuations of a context = one buck
 };
 
 int lm_load_google(const char* dir, uint32_t order, const char* start_symbol, const char* end_symbol, const std::vector<std::string>& alphabet,
-                   HostLM& lm, std::string& err);
+                   int id_order, HostLM& lm, std::string& err);
+int lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_symbol, const char* end_symbol,
+                   const std::vector<std::string>& alphabet, HostLM& lm, std::string& err);
+void lm_level_packed(const HostLM& lm, uint32_t level, std::vector<uint64_t>& containers, std::vector<uint64_t>& values, uint32_t* total);
 int lm_build_google_files(const uint8_t* text, size_t n, uint32_t order, const char* start_symbol, const char* end_symbol,
                           const std::vector<std::string>& alphabet, const std::vector<std::string>& separators, const char* out_dir,
                           std::string& err);

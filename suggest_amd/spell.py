@@ -19,12 +19,31 @@ SPELLCHECKER_INDEX = dict(name="words", ngram_size=3, wrap=("^", "$"), pad="$", 
 class LanguageModel:
     """lm.LanguageModel (pkg/lm/language_model.go) loaded from <dir>/{1..order}-gm (pkg/lm/ngram_reader.go)."""
 
-    def __init__(self, directory, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-.")):
+    def __init__(self, directory=None, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-."),
+                 id_order="lines", binary=None, dictionary=None):
+        """directory + id_order: Google count files; "lines" numbers the words by 1-gm line (the reference's test indexer,
+        indexer.go:88-114), "count" by (count desc, word asc) like the production build (binary.go:101-199).
+        binary + dictionary: RetrieveLMFromBinary (binary.go:59-98) from <name>.lm and <name>.cdb."""
         alpha = (C.c_char_p * len(alphabet))(*[_enc(a) for a in alphabet])
         h = C.c_void_p()
-        _lib.check(_lib.lib().sg_lm_load_google(_enc(directory), int(order), _enc(start_symbol), _enc(end_symbol), alpha, len(alphabet), C.byref(h)))
+        L = _lib.lib()
+        if binary is not None:
+            _lib.check(L.sg_lm_load_binary(_enc(binary), _enc(dictionary), _enc(start_symbol), _enc(end_symbol), alpha, len(alphabet), C.byref(h)))
+        else:
+            _lib.check(L.sg_lm_load_google_ex(_enc(directory), int(order), _enc(start_symbol), _enc(end_symbol), alpha, len(alphabet),
+                                              {"lines": 0, "count": 1}[id_order], C.byref(h)))
         self._h = h
-        self.order = int(order)
+        self.order = int(L.sg_lm_order(h))
+
+    def level(self, i):
+        """-> (containers u64[], values u64[], total): level i in the reference's packed form (packed_array.go:12-16)"""
+        L = _lib.lib()
+        nc, nv, tot = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(L.sg_lm_level(self._h, i, None, 0, C.byref(nc), None, 0, C.byref(nv), C.byref(tot)))
+        c = np.zeros(nc.value, dtype=np.uint64)
+        v = np.zeros(nv.value, dtype=np.uint64)
+        _lib.check(L.sg_lm_level(self._h, i, c.ctypes.data, nc.value, C.byref(nc), v.ctypes.data, nv.value, C.byref(nv), C.byref(tot)))
+        return c, v, int(tot.value)
 
     @staticmethod
     def build_files(text, directory, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-."),
