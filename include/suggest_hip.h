@@ -211,6 +211,15 @@ typedef struct sg_stats {
 } sg_stats;
 int sg_index_stats(const sg_index* index, sg_stats* out);
 
+/* The forward index (doc -> distinct terms) of the primary replica, copied back for documents
+ * first .. first+n-1: out_card[i] = cardinality, out_n[i] = number of distinct terms, out_keys[i*cap ..] their term keys. */
+int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, uint32_t* out_card, uint32_t* out_n,
+                     uint64_t* out_keys);
+
+/* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
+ * SG_FILTER_LEVEL, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
+int sg_index_tune(sg_index* index, const char* knob, int value);
+
 /* Tokens of `text` as the index sees them, one packed 64-bit term key each (DESIGN.md §Term keys);
  * returns the token count (may exceed cap; only cap are written).  NewSuggestTokenizer /
  * NewAutocompleteTokenizer, pkg/suggest/tokenizer.go:9-34. */

@@ -36,10 +36,13 @@ namespace sg {
 #define SG_K_LDS 64
 #define SG_WRAP_MAX 8
 #define SG_ROWS_CAP 512    // u32 entries of seg_off rows kept in LDS per tile
-#define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path
+#define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path (borrowed from the row table)
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
-#define SG_ROWTAB_CAP 96      // row descriptors (16 B) per streaming window
+#define SG_ROWTAB_CAP 84      // row descriptors (8 B + 1 B) per streaming window
+#define SG_QH 192             // slots of the query-term hash (LDS): A <= 128 occurrences, load <= 0.67
+#define SG_CAND_BIG 128       // the candidate queue of launches whose top-k rows leave the room (k <= SG_K_BIGQ)
+#define SG_K_BIGQ 21
 #define SG_MAX_PARTS 32       // parts a heavy query is cut into
 
 struct DeviceIndex {
@@ -63,6 +66,10 @@ struct DeviceIndex {
   const uint32_t* extra_ts;    // [n_extra] term*S+segment of lists holding repeats, ascending
   const uint32_t* extra_cnt;   // [n_extra] raw length - stored length of that list
   const uint32_t* list_len;    // [n_terms*S] stored (de-duplicated) list lengths
+  // forward index (doc -> its distinct terms), derived from the CSR on the device (forward_index.inc): verifying a
+  // candidate is ONE coalesced read of its term list instead of a binary search in every query term's posting list
+  const uint2* fwd_rec;        // [n_docs] {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
+  const uint32_t* fwd_terms;   // term ids, a doc's list padded to a whole chunk with 0xFFFFFFFF
   uint32_t n_dups, n_dup_docs, n_extra;
   uint32_t slot_mask, n_na, n_lower;
   uint32_t S, n_terms, q, n_docs;
@@ -251,6 +258,9 @@ __device__ uint64_t d_mix64(uint64_t k) {
   k ^= k >> 31;
   return k;
 }
+__device__ __forceinline__ uint32_t d_qhash(uint32_t term) { return (((term * 0x9E3779B1u) >> 24) * 3u) >> 2; }   // slot of SG_QH = 192
+__device__ __forceinline__ uint32_t d_qnext(uint32_t h) { return h + 1u == SG_QH ? 0u : h + 1u; }
+static_assert(SG_QH == 192, "d_qhash maps 8 bits onto 3/4 of 256");
 __device__ uint32_t d_term_lookup(const DeviceIndex& ix, uint64_t key) {
   uint32_t h = (uint32_t)d_mix64(key) & ix.slot_mask;
   for (;;) {
@@ -607,21 +617,29 @@ __device__ __forceinline__ void topk_insert(TopK& tk, uint64_t s, uint32_t d, in
   topk_recompute_worst(tk, lane);
 }
 
-// Buckets a group of `postings` postings needs so that a bucket reaching T by chance is rare
-// (a false candidate only costs a slot in the batched verification): postings / lambda(T).
-// m16[level][T] = ceil(16 / lambda): lambda = postings per bucket at which a bucket reaches T by chance with
-// probability 3e-5 / 1e-5 / 3e-6 / 1e-6 (Poisson tail; generated with scipy.stats.poisson).  T > 32 uses T = 32.
-__device__ const uint8_t kBucketsPer16Postings[4][33] = {
+// Buckets a group of `postings` postings needs so that flagged postings that are no matches stay rare: postings / lambda(T).
+// m16[level][T] = ceil(16 / lambda), lambda = postings per bucket (Poisson; tables generated with scipy.stats.poisson):
+//   levels 0-3: a BUCKET reaches T by chance with probability 3e-5 / 1e-5 / 3e-6 / 1e-6 — what a false candidate was worth
+//               when verifying one cost a binary search in every query term's list;
+//   levels 4-7: a POSTING finds T-1 others in its bucket with probability 1e-3 / 3e-3 / 1e-2 / 3e-2 — verification through
+//               the forward index is one 128-byte read, so far more false candidates are affordable: 2-3x fewer buckets, i.e.
+//               larger groups, fewer docID-range passes, deeper list skipping.  T > 32 uses T = 32.
+__device__ const uint8_t kBucketsPer16Postings[8][33] = {
     {255, 255, 255, 255, 95, 47, 28, 19, 14, 11, 9, 7, 6, 6, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2},
     {255, 255, 255, 255, 126, 59, 35, 23, 17, 13, 10, 8, 7, 6, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2},
     {255, 255, 255, 255, 171, 76, 43, 28, 19, 15, 12, 9, 8, 7, 6, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2},
-    {255, 255, 255, 255, 226, 95, 52, 33, 23, 17, 13, 11, 9, 7, 6, 6, 5, 5, 4, 4, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2}};
+    {255, 255, 255, 255, 226, 95, 52, 33, 23, 17, 13, 11, 9, 7, 6, 6, 5, 5, 4, 4, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2},
+    {255, 255, 255, 255, 84, 38, 22, 15, 11, 9, 7, 6, 5, 4, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1},
+    {255, 255, 255, 202, 57, 28, 17, 12, 9, 7, 6, 5, 4, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1},
+    {255, 255, 255, 108, 37, 20, 13, 9, 7, 6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1},
+    {255, 255, 255, 60, 25, 14, 10, 7, 6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1}};
 __device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T, uint32_t level) {
   const uint32_t m16 = kBucketsPer16Postings[level][T < 0 ? 0 : (T > 32 ? 32 : T)];
   return (postings * m16) >> 4;
 }
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 static_assert(SG_UNROLL == 4, "u32x16 below holds 4 rows x 4 postings");
 
 // Counts one batch of SG_UNROLL rows (a row = up to 64 consecutive 16-byte chunks of ONE posting
@@ -666,6 +684,9 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
       }
     }
   }
+  // one wait for all sixteen returns (left alone the compiler may stage it: lgkmcnt(11), (10), (8) ... — fifteen more
+  // instructions in a loop that is issue-bound)
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
   uint32_t mx = 0;
 #pragma unroll
   for (int u = 0; u < SG_UNROLL; u++) {
@@ -729,15 +750,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32*)cnt;   // LDS byte address of the counters (aligned to their size)
   uint32_t* term = cnt + cnt_words;
   uint32_t* rows = term + SG_MAX_A;
-  uint32_t* cand = rows + SG_ROWS_CAP;
-  uint32_t* candw = cand + SG_CAND_CAP;             // segment (within the tile) of each queued candidate
-  uint32_t* rowtab = candw + SG_CAND_CAP + 32;      // 32 words of verdict staging behind the queue, then the row table (16-byte aligned)
-  uint32_t* dummy_w = rowtab + 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL);   // then one
+  const uint32_t cq_cap = a.k <= SG_K_BIGQ ? SG_CAND_BIG : SG_CAND_CAP;   // (the LDS a small k leaves goes to the queue)
+  uint32_t* cq_doc = rows + SG_ROWS_CAP;            // candidate queue: docs whose bucket reached the flag threshold ...
+  uint32_t* cq_jj = cq_doc + cq_cap;                // ... and the query position of the list each was met in (later: the verdict)
+  uint32_t* rowtab = cq_jj + cq_cap;                // the row table: {first chunk, live lanes} per row (8-byte aligned) ...
+  uint8_t* rowlist = (uint8_t*)(rowtab + 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL));   // ... and the list (query position) of each row
+  uint32_t* dummy_w = rowtab + 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2;   // then one
   const uint32_t dummy_lane = (uint32_t)(uintptr_t)(lds_u32*)(dummy_w + lane);   // private dummy counter word per lane
-  uint32_t* dup_scratch = rowtab;                   // the repeated-term path runs between streams: it borrows the row table
-  static_assert(SG_DUP_SCRATCH <= 4 * (SG_ROWTAB_CAP + 2 * SG_UNROLL), "dup scratch must fit the row table");
-  uint32_t* tk_id_lds = dummy_w + 64;
-  uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + SG_K_LDS);
+  // the query's terms as an LDS hash (linear probing; an occurrence = an entry, so a repeated term sits in consecutive
+  // probe slots): what a candidate's own term list (forward index) is matched against
+  uint32_t* qh_key = dummy_w + 64;
+  uint8_t* qh_pos = (uint8_t*)(qh_key + SG_QH);     // query position of the entry
+  // the repeated-term path (documents that repeat a term: rare) borrows row table + dummies + hash — all idle while
+  // candidates are emitted — and rebuilds the hash afterwards
+  uint32_t* dup_scratch = rowtab;
+  static_assert(SG_DUP_SCRATCH <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64 + SG_QH + SG_QH / 4,
+                "dup scratch must fit row table + dummies + hash");
+  uint32_t* tk_id_lds = qh_key + SG_QH + SG_QH / 4; // top-k rows: min(k, SG_K_LDS) ids, then as many 64-bit scores
+  uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + ((min(a.k, (uint32_t)SG_K_LDS) + 1u) & ~1u));
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
   uint64_t* keys = (uint64_t*)(cnt + SG_MAX_RUNES);
@@ -778,6 +808,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; break; }
   if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; break; }
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; break; }
+  auto build_qhash = [&]() {
+    for (uint32_t i = lane; i < SG_QH; i += 64) qh_key[i] = kNoTerm;
+    __syncthreads();
+    for (int i = lane; i < A; i += 64) {
+      const uint32_t x = term[i];
+      if (x == kNoTerm) continue;
+      for (uint32_t h = d_qhash(x);; h = d_qnext(h))
+        if (atomicCAS(qh_key + h, kNoTerm, x) == kNoTerm) { qh_pos[h] = (uint8_t)i; break; }
+    }
+    __syncthreads();
+  };
+  build_qhash();
 
   const int S = (int)ix.S;
   int b_min, b_max;
@@ -882,104 +924,158 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     PH(1)
 
-    // ---- candidate queue of the tile: docs whose bucket reached the flag threshold wait here and are
-    //      verified together (their binary searches overlap in flight) instead of stalling the stream ----
+    // ---- candidate queue: docs whose bucket reached the flag threshold wait here (with the query position of the list
+    //      they were met in) and are verified together at the end of their group — or earlier when the queue fills ----
     uint32_t qn = 0;
+    uint64_t str_m[2] = {0, 0};                                 // query positions whose list the current group streams
+    uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;                  // docID range of the current pass
     auto offer = [&](uint32_t d, int overlap, int w) {
       if (kLM)                                                              // lmCollector: score = ScoreNext(doc), monotone in the count
         topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
       else if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);     // score = -docID, collector.go:104-106
       else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
     };
-    auto emit_secondaries = [&](uint32_t d, int w, int T, uint64_t fm0, uint64_t fm1) {
-      __syncthreads();
-      const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T, d, fm0, fm1, lane);
-      const uint32_t* extra = dup_scratch + 2 * SG_MAX_A + 64;
-      for (int x = 0; x < n_extra; x++) offer(d, (int)extra[x], w);
-      __syncthreads();
+    // which query-term occurrences hold doc d in segment w, by binary search in their lists: only documents that repeat a
+    // term come here (the secondary entries of SURVEY.md §A.3 need the per-list view)
+    auto exact_masks = [&](uint32_t d, int w, uint64_t (&fm)[2]) -> int {
+      fm[0] = fm[1] = 0;
+      int c = 0;
+      for (int r = 0; r < a_rounds; r++) {
+        const int i = r * 64 + lane;
+        bool found = false;
+        if (i < A) {
+          const uint32_t s0 = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0;
+          if (nch) {
+            const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
+            uint32_t lo = 0, hi = nch * 4;
+            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
+            found = lo < nch * 4 && p[lo] == d;
+          }
+        }
+        const uint64_t m = ballot(found);
+        c += (int)popc64(m);
+        if (r == 0) fm[0] = m; else fm[1] = m;
+      }
+      return c;
     };
-    auto emit = [&](uint32_t d, int overlap, int w, uint64_t fm0, uint64_t fm1) {
+    auto emit = [&](uint32_t d, int overlap, int w) {
       const int T = (int)readlane((uint32_t)seg_T, w);
+      if (DBG_SKIP(2048u)) { topk_insert(tk, score_bits((double)overlap + (double)T / 1000.0 + (double)w / 1e6), d, lane); return; }
       if (overlap < T) return;
       DBG_COUNT(5, 1)
       offer(d, overlap, w);
       if (ix.n_dup_docs) {                                  // dictionaries whose docs never repeat a term skip this
-        if ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u) emit_secondaries(d, w, T, fm0, fm1);
+        if ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u) {
+          uint64_t fm[2];
+          __syncthreads();
+          exact_masks(d, w, fm);
+          const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T, d, fm[0], fm[1], lane);
+          const uint32_t* extra = dup_scratch + 2 * SG_MAX_A + 64;
+          for (int x = 0; x < n_extra; x++) offer(d, (int)extra[x], w);
+          __syncthreads();
+          build_qhash();                                    // (the scratch lay over it)
+        }
       }
     };
+    // Verification through the forward index: a candidate's own term list (one contiguous read) is matched against the
+    // query-term hash.  Lanes are (candidate, term slot) pairs, 64/gsz candidates side by side, 4 interleaved per lane.
+    //   overlap = sum over the doc's distinct terms of their occurrences in the query   (query-side repeats
+    //             count per occurrence, doc-side once)
+    // A matching doc is flagged in every streamed list from its T'-th on; it is emitted ONCE — at its occurrence in the LAST
+    // streamed list that holds it (bucket counts only grow, so that occurrence is always flagged): `later` = some streamed
+    // query position behind the one it was met in holds one of its terms.  No dedup set, no bound on candidates per group.
     auto flush_queue = [&]() {
+      if (qn == 0) return;
       PH(2)
       __syncthreads();
-      // Lanes are (candidate, query term) pairs: with A <= 32 terms 64/gsz candidates are verified side by side, each lane
-      // running 4 of them interleaved (their dependent loads overlap) — up to 32 candidates per round of binary searches
-      // instead of 4.  Dictionaries of near-duplicates (product names) queue dozens of candidates per query.
-      const int gsz = a_rounds > 1 ? 64 : (A <= 8 ? 8 : A <= 16 ? 16 : A <= 32 ? 32 : 64), ngrp = 64 / gsz;
+      for (uint32_t base = 0; base < qn; base += 64) {          // 64 candidates (one per lane for the record loads) at a time
+      const uint32_t n = min(64u, qn - base);
+      uint32_t* qd = cq_doc + base;
+      uint32_t* qj = cq_jj + base;
+      const uint32_t my_doc = (uint32_t)lane < n ? qd[lane] : 0u;
+      const uint32_t my_jj = (uint32_t)lane < n ? qj[lane] : 0u;
+      uint2 rec = make_uint2(0u, 0u);
+      if ((uint32_t)lane < n) rec = ix.fwd_rec[my_doc];
+      uint32_t nd_max = rec.y >> 16;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) nd_max = max(nd_max, (uint32_t)__shfl_xor((int)nd_max, off, 64));
+      const int gsz = nd_max <= 8u ? 8 : nd_max <= 16u ? 16 : nd_max <= 32u ? 32 : 64, ngrp = 64 / gsz;
       const int gi = lane / gsz, ti = lane - gi * gsz;
-      uint32_t* stage = cnt;                                      // verdicts: the counters are idle between groups
-      for (uint32_t c0 = 0; c0 < qn; c0 += 4u * (uint32_t)ngrp) {
-        uint32_t qd[4], qw[4];
-        bool ok[4];
+      const uint64_t gmask = gsz == 64 ? ~0ull : ((1ull << gsz) - 1ull) << (gi * gsz);
+      for (uint32_t c0 = 0; c0 < n; c0 += 4u * (uint32_t)ngrp) {
+        uint32_t cc[4], c_off[4], c_nd[4], c_jj[4];
         int ov[4] = {0, 0, 0, 0};
-        uint64_t fmask[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        bool late[4] = {false, false, false, false};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const uint32_t c = c0 + (uint32_t)(j * ngrp + gi);
-          ok[j] = c < qn; qd[j] = ok[j] ? cand[c] : 0u; qw[j] = ok[j] ? candw[c] : 0u;
+          cc[j] = c0 + (uint32_t)(j * ngrp + gi);
+          const int src = (int)(min(cc[j], 63u) << 2);           // every lane takes part in the permutes
+          // (ds_bpermute returns 0 from a source lane that is switched off: the permutes must not end up under a branch —
+          //  a candidate's record lives in lane cc[j], which may belong to a lane group with nothing to do this round)
+          c_off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.x);
+          const uint32_t ry = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.y);
+          c_jj[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)my_jj);
+          asm volatile("" : "+v"(c_off[j]), "+v"(c_jj[j]) : "v"(ry));      // pin the three permutes here, unpredicated
+          c_nd[j] = cc[j] < n ? ry >> 16 : 0u;
         }
-        for (int r = 0; r < a_rounds; r++) {
-          const int i = r * 64 + ti;
-          uint32_t lo[4], hi[4], n4[4];
-          const uint32_t* pp[4];
+        for (uint32_t s0 = 0; s0 < nd_max; s0 += (uint32_t)gsz) {   // one round unless a document has more than 64 distinct terms
+          uint32_t x[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            lo[j] = 0; hi[j] = 0; n4[j] = 0; pp[j] = ix.postings;
-            if (i < A && ok[j]) {
-              const uint32_t s0 = rows[i * stride + qw[j]];
-              n4[j] = (rows[i * stride + qw[j] + 1] - s0) * 4u;
-              hi[j] = n4[j];
-              pp[j] = ix.postings + (uint64_t)s0 * 4;
-            }
+            const uint32_t slot = s0 + (uint32_t)ti;
+            x[j] = slot < c_nd[j] ? ix.fwd_terms[(uint64_t)c_off[j] * 4u + slot] : kNoTerm;
           }
-          for (int step = 0; step < 32; step++) {
-            bool act = false;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (lo[j] < hi[j]) {
-                const uint32_t mid = (lo[j] + hi[j]) >> 1;
-                if (pp[j][mid] < qd[j]) lo[j] = mid + 1; else hi[j] = mid;
-                act = true;
+          for (int j = 0; j < 4; j++) {
+            uint32_t mult = 0;
+            bool lt = false;
+            if (x[j] != kNoTerm) {
+              for (uint32_t h = d_qhash(x[j]);; h = d_qnext(h)) {
+                const uint32_t kx = qh_key[h];
+                if (kx == kNoTerm) break;
+                if (kx == x[j]) {
+                  const uint32_t pp = qh_pos[h];
+                  mult++;
+                  lt |= pp > c_jj[j] && (((pp < 64u ? str_m[0] : str_m[1]) >> (pp & 63u)) & 1ull);
+                }
               }
             }
-            if (!ballot(act)) break;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const bool found = lo[j] < n4[j] && pp[j][lo[j]] == qd[j];
-            uint64_t fmj = ballot(found);
-            if (gsz < 64) fmj = (fmj >> (gi * gsz)) & ((1ull << gsz) - 1ull);   // this candidate's lanes: bit = term
-            ov[j] += (int)popc64(fmj);
-            if (r == 0) fmask[j][0] = fmj; else fmask[j][1] = fmj;
+            const uint64_t mm = ballot(mult != 0u);
+            ov[j] += (int)popc64(mm & gmask);
+            uint64_t m2 = ballot(mult > 1u);                     // a query that repeats a term: the extra occurrences
+            while (m2) {
+              const int l = __builtin_ctzll(m2);
+              m2 &= m2 - 1;
+              const uint32_t extra = readlane(mult, l) - 1u;
+              if (l / gsz == gi) ov[j] += (int)extra;
+            }
+            late[j] |= (ballot(lt) & gmask) != 0ull;
           }
         }
-        // stage the verdicts in LDS (queue slots are consumed) so that emit() is instantiated once
-        __syncthreads();
+        // verdict into the queue slot (consumed): bit 31 = emit, bits 8..23 cardinality, bits 0..7 overlap
         if (ti == 0) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            uint32_t* st = stage + (j * ngrp + gi) * 8;
-            st[0] = qd[j]; st[1] = (uint32_t)ov[j]; st[2] = qw[j]; st[3] = ok[j] ? 1u : 0u;
-            st[4] = (uint32_t)fmask[j][0]; st[5] = (uint32_t)(fmask[j][0] >> 32);
-            st[6] = (uint32_t)fmask[j][1]; st[7] = (uint32_t)(fmask[j][1] >> 32);
+            if (cc[j] < n) {
+              const uint32_t dd = qd[cc[j]];
+              const bool keep = !late[j] && dd >= lo_doc && dd < hi_doc;
+              qj[cc[j]] = keep ? (0x80000000u | (uint32_t)ov[j]) : 0u;
+            }
           }
         }
-        __syncthreads();
-        const int n_staged = 4 * ngrp;
+      }
+      __syncthreads();
 #pragma nounroll
-        for (int j = 0; j < n_staged; j++) {
-          const uint32_t* st = stage + j * 8;
-          const uint32_t s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5], s6 = st[6], s7 = st[7];
-          if (s3) emit(s0, (int)s1, (int)s2, (uint64_t)s4 | ((uint64_t)s5 << 32), (uint64_t)s6 | ((uint64_t)s7 << 32));
-        }
+      for (uint32_t c = 0; c < n; c++) {
+        const uint32_t v = qj[c];
+        DBG_COUNT(7, 1)
+        if (DBG_SKIP(4096u)) { topk_insert(tk, score_bits((double)(v & 0xFFu) + (double)c / 1000.0 + (double)n / 1e6 + (v >> 31 ? 0.5 : 0.0)), qd[c], lane); continue; }
+        if (!(v >> 31)) continue;
+        DBG_COUNT(6, 1)
+        const uint32_t card = readlane(rec.y, (int)c) & 0xFFFFu;
+        emit(qd[c], (int)(v & 0xFFu), (int)card - tb);
+      }
+      __syncthreads();
       }
       PH(4)
       qn = 0;
@@ -1067,66 +1163,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const uint32_t lg_max = u8 ? a.log2_cnt + 2 : a.log2_cnt;
         while (lg < lg_max && (1u << lg) < need) lg++;
       }
-      if (qn > SG_CAND_CAP - 16) flush_queue();
-      DBG_COUNT(0, 1) DBG_COUNT(6, L - Leff) DBG_COUNT(7, L)
-      const uint32_t q0 = qn;                                  // this group's candidates: cand[q0 .. qn)
-      bool overflow = false, saturated = false;
-
-      // exact overlap of doc d, found in list jj at chunk `chunk` of the posting store: locate its
-      // segment, then count the query-term occurrences whose list in that segment contains d
-      auto verify = [&](uint32_t d, uint32_t jj, uint32_t chunk, int* seg_w, int* last_list, uint64_t (&fm)[2]) -> int {
-        fm[0] = fm[1] = 0;
-        int w = g0;
-        while (w < g1 && rows[jj * stride + w + 1] <= chunk) w++;
-        *seg_w = w;
-        int c = 0, last = -1;
-        for (int r = 0; r < a_rounds; r++) {
-          const int i = r * 64 + lane;
-          bool found = false;
-          if (i < A) {
-            const uint32_t s0 = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0;
-            if (nch) {
-              const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
-              uint32_t lo = 0, hi = nch * 4;
-              while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
-              found = lo < nch * 4 && p[lo] == d;
-            }
-          }
-          const uint64_t m = ballot(found);
-          c += (int)popc64(m);
-          if (r == 0) fm[0] = m; else fm[1] = m;
-          if (m) last = r * 64 + 63 - __builtin_clzll(m);
-        }
-        *last_list = last;
-        return c;
-      };
-      auto in_cand = [&](uint32_t dd) -> bool {
-        bool seen = false;
-        for (uint32_t i = q0 + lane; i < qn; i += 64) seen |= cand[i] == dd;
-        return ballot(seen) != 0;
-      };
-      auto on_flag = [&](uint32_t dd, uint32_t jj, uint32_t chunk) {   // dd flagged in list jj at posting-store chunk
-        if (in_cand(dd)) return;
-        if (qn == SG_CAND_CAP) { overflow = true; return; }
-        int w = g0;                                            // segment of dd: where list jj holds `chunk`
-        while (w < g1 && rows[jj * stride + w + 1] <= chunk) w++;
-        if (lane == 0) { cand[qn] = dd; candw[qn] = (uint32_t)w; }
-        qn++;
-        DBG_COUNT(3, 1)
-        __syncthreads();
-      };
-      // slow path of one counted batch whose row descriptors are rows4[0..3]; visits only the
-      // flagged postings (per-lane bit mask, then uniform dynamic indexing of the register vectors)
+      DBG_COUNT(0, 1)
+      bool saturated = false, overflow = false;
+      // the group's streamed lists as a mask over query positions (what `later` in flush_queue is asked against)
+      str_m[0] = ballot(ln_r[0] != 0u) & ~skip_m[0];
+      str_m[1] = a_rounds > 1 ? ballot(ln_r[1] != 0u) & ~skip_m[1] : 0ull;
+      // slow path of one counted batch whose row descriptors are rows4[0..3]: the flagged postings go to the queue
+      // (per posting slot one ballot + a prefix count: the lanes store their own postings)
       auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
-                         const uint4* rows4, uint32_t Tm1) {
+                         uint32_t row0, uint32_t Tm1) {
         const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
                            v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
-        const uint4 t0 = rows4[0], t1 = rows4[1], t2 = rows4[2], t3 = rows4[3];   // the batch's row descriptors (LDS)
-        const uint32_t __attribute__((ext_vector_type(4))) jv = {t0.z, t1.z, t2.z, t3.z};
-        const uint32_t __attribute__((ext_vector_type(4))) cv = {t0.x, t1.x, t2.x, t3.x};
         uint32_t fl = 0;
 #pragma unroll
-        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) fl |= ((live[ue >> 2] && was[ue] >= Tm1) ? 1u : 0u) << ue;
+        for (int ue = 0; ue < 4 * SG_UNROLL; ue++)       // (a list's last chunk is padded with copies of its last docID: one posting, not four)
+          fl |= ((live[ue >> 2] && was[ue] >= Tm1 && !((ue & 3) && vv[ue] == vv[ue - 1])) ? 1u : 0u) << ue;
         if (u8) {
           // a u8 counter about to wrap would carry into its neighbour and — worse — undercount its own bucket.  Every
           // increment returns the value it found, and a counter passes through every value on its way up, so "some
@@ -1137,17 +1188,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           for (int ue = 0; ue < 4 * SG_UNROLL; ue++) hot |= (live[ue >> 2] && was[ue] >= 250u) ? 1u : 0u;
           if (ballot(hot != 0)) saturated = true;
         }
-        uint64_t lanes = ballot(fl != 0);
-        while (lanes) {
-          const int l = __builtin_ctzll(lanes);
-          lanes &= lanes - 1;
-          uint32_t f = readlane(fl, l);
-          while (f) {
-            const int ue = __builtin_ctz(f);
-            f &= f - 1;
-            DBG_COUNT(2, 1)
-            on_flag(readlane(vv[ue], l), jv[ue >> 2], cv[ue >> 2] + (uint32_t)l);
-          }
+        if (overflow) return;                                    // (the saturation watch above goes on)
+#pragma nounroll
+        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {             // (vv[ue]: a uniform dynamic index into the register vector)
+          const bool mine = (fl >> ue) & 1u;
+          const uint64_t m = ballot(mine);
+          if (!m) continue;
+          const uint32_t cnt_f = popc64(m);
+          DBG_COUNT(2, cnt_f)
+          // a full queue is not emptied here (verification in the middle of the stream loop costs the loop its registers):
+          // the group's flagged postings are collected again after the stream, from the final counters
+          if (qn + cnt_f > cq_cap || DBG_SKIP(1024u)) { overflow = true; break; }
+          DBG_COUNT(3, cnt_f)
+          const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = rowlist[row0 + (uint32_t)(ue >> 2)]; }
+          qn += cnt_f;
         }
       };
 
@@ -1161,7 +1216,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
       uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
       uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
-      uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;
+      lo_doc = 0; hi_doc = 0xFFFFFFFFu;
       for (uint32_t pass = 0; pass < n_pass; pass++) {
       DBG_COUNT(4, 1)
       if (n_pass > 1) {
@@ -1232,9 +1287,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           prev_lo[r] = lo;
         }
         lg = u8 ? a.log2_cnt + 2 : a.log2_cnt;                 // all buckets for every pass
-        overflow = false;
       }
       // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
+      saturated = false; overflow = false;
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
         for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
@@ -1255,7 +1310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           pr[r] = n_rows + incl - nr[r];
           n_rows += readlane(incl, 63);
         }
-        uint4* rowtab4 = (uint4*)rowtab;
+        uint2* rowtab2 = (uint2*)rowtab;
         for (uint32_t w0 = 0; w0 < n_rows && !DBG_SKIP(512u); w0 += SG_ROWTAB_CAP) {
           const uint32_t wn = min((uint32_t)SG_ROWTAB_CAP, n_rows - w0);
           __syncthreads();
@@ -1264,19 +1319,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (r < a_rounds) {
               for (uint32_t x = 0; x < nr[r]; x++) {
                 const uint32_t R = pr[r] + x;
-                if (R >= w0 && R < w0 + wn)
-                  rowtab4[R - w0] = make_uint4(ls_r[r] + x * 64u, min(64u, ln_r[r] - x * 64u), (uint32_t)(r * 64 + lane), 0u);
+                if (R >= w0 && R < w0 + wn) {
+                  rowtab2[R - w0] = make_uint2(ls_r[r] + x * 64u, min(64u, ln_r[r] - x * 64u));
+                  rowlist[R - w0] = (uint8_t)(r * 64 + lane);
+                }
               }
             }
           }
-          if (lane < 2 * SG_UNROLL) rowtab4[wn + lane] = make_uint4(0u, 0u, 0u, 0u);   // dead rows behind the last batch
+          if (lane < 2 * SG_UNROLL) rowtab2[wn + lane] = make_uint2(0u, 0u);   // dead rows behind the last batch
           __syncthreads();
           // The row loads are issued and awaited by hand (inline asm): the compiler's own wait-count insertion kept the
           // "wait for this batch only, the next one stays in flight" schedule for a while and then — after an unrelated
           // change elsewhere in the kernel — fell back to s_waitcnt vmcnt(0) right behind the prefetch (−5 % on the
           // headline).  vmcnt counts in issue order, so vmcnt(4) with the 4 loads of the next batch behind them means
           // "these four are here" whatever else is in flight.
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          typedef u32x4v u32x4;
           u32x4 v[SG_UNROLL], vn[SG_UNROLL];
           uint32_t live[SG_UNROLL], liven[SG_UNROLL];
           u32x16 was;
@@ -1284,7 +1341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           auto fetch = [&](u32x4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL]) {
 #pragma unroll
             for (int u = 0; u < SG_UNROLL; u++) {
-              const uint4 t = rowtab4[next_row + (uint32_t)u];   // uniform address: one broadcast LDS read
+              const uint2 t = rowtab2[next_row + (uint32_t)u];   // uniform address: one broadcast LDS read
               lv[u] = (uint32_t)lane < t.y ? 1u : 0u;
               const uint4* src = post4 + (t.x + min((uint32_t)lane, t.y ? t.y - 1 : 0u));
               asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vv[u]) : "v"(src) : "memory");
@@ -1300,7 +1357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
             else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
             DBG_COUNT(1, 1)
-            if (any) { PH(5) flagged(pv, pl, was, rowtab4 + row0, Tm1); PH(6) }
+            if (any) { PH(5) flagged(pv, pl, was, row0, Tm1); PH(6) }
           };
           // fetches are unconditional (rows past the last are dead rows: they load chunk 0): every process() has the four
           // loads of the following batch behind its own
@@ -1317,145 +1374,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         PH(5)
         if (!(u8 && saturated)) break;
-        // re-run with u32 counters: candidates already verified stay in the dedup set (emitted once)
+        // A u8 counter came close to wrapping: the group is counted again with u32 counters (nothing of it has reached
+        // the top-k yet: its candidates are only queued)
+        qn = 0; overflow = false;
         u8 = false; saturated = false;
         lg = min(lg, a.log2_cnt);
         __syncthreads();
       }
-
       if (overflow) {
-        // More distinct candidates than the dedup set holds: second pass over the final counters; every remaining doc
-        // is handled exactly once, at its occurrence in the last list holding it (padding repeats a list's last doc
-        // inside its last chunk: skipped as equal neighbours).  A matching doc is flagged once per list, so a query
-        // with hundreds of matches flags thousands of postings: they are collected 32 at a time and verified side by
-        // side (lanes = candidate x term, 4 interleaved per lane) — one site, so emit()/verify() keep one instance.
+        // More flagged postings than the queue holds (dictionaries of near-duplicates: dozens of matches per query, each
+        // flagged in every list from its T'-th on).  The lists are walked again against the FINAL counters — a superset of
+        // what the stream flagged, counts only grow — and the queue is emptied whenever it fills; the verdict rule (emit at
+        // the last streamed list holding the doc) keeps every document single.
+        qn = 0;
         __syncthreads();
-        uint32_t* p2_doc = dummy_w;                                // [32]  (the lanes' dummy counter words: idle outside the stream)
-        uint32_t* p2_w = dummy_w + 32;                             // [32]  segment within the tile
-        uint32_t* p2_list = candw + SG_CAND_CAP;                   // [32]  list the doc was met in (the staging words behind the queue)
-        uint32_t* p2_v = rowtab;                                   // [32]  verdict: overlap, or ~0 (not here / not this list)
-        uint32_t n_p2 = 0;
-        const int gsz = a_rounds > 1 ? 64 : (A <= 8 ? 8 : A <= 16 ? 16 : A <= 32 ? 32 : 64), ngrp = 64 / gsz;
-        const int gi = lane / gsz, ti = lane - gi * gsz;
-        for (int i = 0; i <= A; i++) {                             // i == A: nothing to stream, flushes what is left
-          const bool fin = i == A;
+        for (int i = 0; i < A; i++) {
           const int r = (i >> 6) & 1, li = i & 63;
-          const uint32_t s = fin ? 0u : readlane(r ? ls_r[1] : ls_r[0], li), n = fin ? 1u : readlane(r ? ln_r[1] : ln_r[0], li);
+          if (!(((r ? str_m[1] : str_m[0]) >> li) & 1ull)) continue;
+          const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li);
           for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t c = c0 + lane;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (!fin && c < n) v = post4[s + c];
+            if (c < n) v = post4[s + c];
 #pragma nounroll
             for (int e = 0; e < 4; e++) {
               const uint32_t d = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
               const uint32_t dprev = e == 1 ? v.x : e == 2 ? v.y : v.z;
               bool flag = false;
-              if (!fin && c < n && !(e > 0 && d == dprev)) {
+              if (c < n && !(e > 0 && d == dprev)) {
                 const uint32_t bk = d & ((1u << lg) - 1u);
                 const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
                 flag = now >= (uint32_t)Teff;
               }
-              uint64_t m = ballot(flag);
-              for (bool more = true; more;) {
-                if (m) {
-                  const int l = __builtin_ctzll(m);
-                  m &= m - 1;
-                  const uint32_t dd = readlane(d, l);
-                  if (!in_cand(dd)) {
-                    const uint32_t chunk = s + c0 + (uint32_t)l;
-                    int w = g0;                                    // segment of dd: where list i holds `chunk`
-                    while (w < g1 && rows[i * stride + w + 1] <= chunk) w++;
-                    if (lane == 0) { p2_doc[n_p2] = dd; p2_w[n_p2] = (uint32_t)w; p2_list[n_p2] = (uint32_t)i; }
-                    n_p2++;
-                  }
-                }
-                more = m != 0;
-                if (n_p2 == 32u || (fin && e == 3 && !more && n_p2)) {
-                  __syncthreads();
-                  for (uint32_t b0 = 0; b0 < n_p2; b0 += 4u * (uint32_t)ngrp) {
-                    uint32_t qd[4], qw[4];
-                    bool ok[4];
-                    int ov[4] = {0, 0, 0, 0}, last[4] = {-1, -1, -1, -1};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                      const uint32_t cc = b0 + (uint32_t)(j * ngrp + gi);
-                      ok[j] = cc < n_p2; qd[j] = ok[j] ? p2_doc[cc] : 0u; qw[j] = ok[j] ? p2_w[cc] : 0u;
-                    }
-                    for (int rr = 0; rr < a_rounds; rr++) {
-                      const int it = rr * 64 + ti;
-                      uint32_t lo4[4], hi4[4], n4[4];
-                      const uint32_t* pp[4];
-#pragma unroll
-                      for (int j = 0; j < 4; j++) {
-                        lo4[j] = 0; hi4[j] = 0; n4[j] = 0; pp[j] = ix.postings;
-                        if (it < A && ok[j]) {
-                          const uint32_t s0 = rows[it * stride + qw[j]];
-                          n4[j] = (rows[it * stride + qw[j] + 1] - s0) * 4u;
-                          hi4[j] = n4[j];
-                          pp[j] = ix.postings + (uint64_t)s0 * 4;
-                        }
-                      }
-                      for (int step = 0; step < 32; step++) {
-                        bool act = false;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                          if (lo4[j] < hi4[j]) {
-                            const uint32_t mid = (lo4[j] + hi4[j]) >> 1;
-                            if (pp[j][mid] < qd[j]) lo4[j] = mid + 1; else hi4[j] = mid;
-                            act = true;
-                          }
-                        }
-                        if (!ballot(act)) break;
-                      }
-#pragma unroll
-                      for (int j = 0; j < 4; j++) {
-                        const bool found = lo4[j] < n4[j] && pp[j][lo4[j]] == qd[j];
-                        uint64_t fmj = ballot(found);
-                        if (gsz < 64) fmj = (fmj >> (gi * gsz)) & ((1ull << gsz) - 1ull);
-                        ov[j] += (int)popc64(fmj);
-                        if (fmj) last[j] = rr * 64 + 63 - __builtin_clzll(fmj);
-                      }
-                    }
-                    if (ti == 0) {
-#pragma unroll
-                      for (int j = 0; j < 4; j++) {
-                        const uint32_t cc = b0 + (uint32_t)(j * ngrp + gi);
-                        if (ok[j]) p2_v[cc] = (last[j] == (int)p2_list[cc] && qd[j] >= lo_doc && qd[j] < hi_doc) ? (uint32_t)ov[j] : 0xFFFFFFFFu;
-                      }
-                    }
-                  }
-                  __syncthreads();
-                  uint32_t dup_mask = 0;                           // docs that repeat a term: the full path below (rare)
-                  for (uint32_t cc = 0; cc < n_p2; cc++) {
-                    const uint32_t vv = p2_v[cc];
-                    if (vv == 0xFFFFFFFFu) continue;
-                    const uint32_t dd = p2_doc[cc];
-                    const int w = (int)p2_w[cc];
-                    if (ix.n_dup_docs && ((ix.dup_bits[dd >> 5] >> (dd & 31u)) & 1u)) { dup_mask |= 1u << cc; continue; }
-                    if ((int)vv < (int)readlane((uint32_t)seg_T, w)) continue;
-                    DBG_COUNT(5, 1)
-                    offer(dd, (int)vv, w);
-                  }
-                  while (dup_mask) {
-                    const uint32_t cc = (uint32_t)__builtin_ctz(dup_mask);
-                    dup_mask &= dup_mask - 1;
-                    const uint32_t dd = p2_doc[cc], jj = p2_list[cc];
-                    int w, lastl;
-                    uint64_t fm[2];
-                    const int ovl = verify(dd, jj, rows[jj * stride + p2_w[cc]], &w, &lastl, fm);
-                    emit(dd, ovl, w, fm[0], fm[1]);
-                  }
-                  n_p2 = 0;
-                  __syncthreads();
-                }
-              }
+              const uint64_t m = ballot(flag);
+              if (!m) continue;
+              const uint32_t cnt_f = popc64(m);
+              DBG_COUNT(3, cnt_f)
+              if (qn + cnt_f > cq_cap) flush_queue();
+              const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              if (flag) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i; }
+              qn += cnt_f;
             }
           }
         }
       }
+      flush_queue();                                            // this pass's candidates (they are judged against its lists and range)
       }  // docID-range passes
     }
-    flush_queue();
   }
 
   // ---- a part of a split query hands its top-k over; the part that finishes last merges them all (top-k of a
@@ -1513,6 +1478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
+  if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 2] = (uint32_t)(qe - qb); out_ids[k - 3] = qi; out_ids[k - 4] = (uint32_t)qb; }
   PH(7)
   } while (0);
   if (!kParts) break;

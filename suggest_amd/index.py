@@ -108,6 +108,20 @@ class NGramIndex:
             self.device = int(devices[0])
         return self
 
+    def forward(self, first, n, cap=160):
+        """-> (card[n], n_terms[n], keys[n, cap]) of the device's forward index (doc -> distinct term keys)"""
+        card = np.zeros(n, dtype=np.uint32); nt = np.zeros(n, dtype=np.uint32); keys = np.zeros((n, cap), dtype=np.uint64)
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_forward(h, int(first), int(n), int(cap), card.ctypes.data, nt.ctypes.data, keys.ctypes.data))
+        return card, nt, keys
+
+    def tune(self, **knobs):
+        """sg_index_tune: e.g. tune(SG_T_FLOOR=6, SG_FILTER_LEVEL=5) — results never depend on the knobs"""
+        with self._use() as h:
+            for k, v in knobs.items():
+                _lib.check(_lib.lib().sg_index_tune(h, k.encode(), int(v)))
+        return self
+
     def replicas(self):
         out = (C.c_int * 64)()
         with self._use() as h:
