@@ -130,7 +130,7 @@ inline std::shared_ptr<Dictionary> OpenCDBDictionary(const std::string& path) {
     return v;
   };
   uint32_t end = 0xFFFFFFFFu;
-  for (int i = 0; i < 256; i++) end = std::min(end, u32(8 * (size_t)i));
+  for (int i = 0; i < 256; i++) if (u32(8 * (size_t)i + 4)) end = std::min(end, u32(8 * (size_t)i));   // (an empty table carries no position)
   std::map<uint32_t, std::string> rec;
   size_t pos = 2048;
   while (pos + 8 <= end && pos + 8 <= data.size()) {

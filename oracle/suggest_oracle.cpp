@@ -24,6 +24,9 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
+#include <cstdio>
+#include <iterator>
 #include <string>
 #include <unordered_map>
 #include <utility>

@@ -56,61 +56,61 @@ def lib():
                           "or `make -C suggest_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
-    L.sg_index_build.argtypes = [vp, vp, u32, C.POINTER(SgDesc), C.POINTER(vp)]
-    L.sg_index_build_device.argtypes = [vp, vp, u32, C.POINTER(SgDesc), i32, C.POINTER(vp)]
-    L.sg_index_build_ex.argtypes = [vp, vp, u32, C.POINTER(SgDesc), u32, i32, C.POINTER(vp)]
-    L.sg_index_digest.argtypes = [vp, vp]
-    L.sg_index_load_reference.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SgDesc), C.POINTER(vp)]
-    L.sg_index_upload.argtypes = [vp, i32]
-    L.sg_index_replicate.argtypes = [vp, vp, u32]
-    L.sg_index_tune.argtypes = [vp, C.c_char_p, i32]
-    L.sg_index_forward.argtypes = [vp, u32, u32, u32, vp, vp, vp]
-    L.sg_index_replicas.argtypes = [vp, vp, u32]
-    L.sg_index_replicas.restype = u32
-    L.sg_suggest_batch.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
-    L.sg_suggest_batch_multi.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
-    L.sg_autocomplete_batch_multi.argtypes = [vp, vp, vp, u32, u32, vp, vp]
-    L.sg_suggest_one.argtypes = [vp, C.c_char_p, u32, i32, dbl, u32, vp, vp, vp]
-    L.sg_autocomplete_one.argtypes = [vp, C.c_char_p, u32, u32, vp, vp]
-    L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
-    L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
-    L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
-    L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
-    L.sg_lm_load_google_ex.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp)]
-    L.sg_lm_load_binary.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
-    L.sg_lm_level.argtypes = [vp, u32, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
-    L.sg_lm_order.argtypes = [vp]
-    L.sg_lm_order.restype = u32
-    L.sg_lm_build_google.argtypes = [C.c_char_p, u64, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p]
-    L.sg_lm_retain.argtypes = [vp]
-    L.sg_lm_retain.restype = None
-    L.sg_lm_release.argtypes = [vp]
-    L.sg_lm_release.restype = None
-    L.sg_lm_num_words.argtypes = [vp]
-    L.sg_lm_num_words.restype = u32
-    L.sg_lm_word.argtypes = [vp, u32, C.c_char_p, u32]
-    L.sg_lm_word_id.argtypes = [vp, C.c_char_p, u32]
-    L.sg_lm_word_id.restype = u32
-    for f in (L.sg_lm_score, L.sg_lm_score_word_ids):
+    if hasattr(L, "sg_index_build"): L.sg_index_build.argtypes = [vp, vp, u32, C.POINTER(SgDesc), C.POINTER(vp)]
+    if hasattr(L, "sg_index_build_device"): L.sg_index_build_device.argtypes = [vp, vp, u32, C.POINTER(SgDesc), i32, C.POINTER(vp)]
+    if hasattr(L, "sg_index_build_ex"): L.sg_index_build_ex.argtypes = [vp, vp, u32, C.POINTER(SgDesc), u32, i32, C.POINTER(vp)]
+    if hasattr(L, "sg_index_digest"): L.sg_index_digest.argtypes = [vp, vp]
+    if hasattr(L, "sg_index_load_reference"): L.sg_index_load_reference.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SgDesc), C.POINTER(vp)]
+    if hasattr(L, "sg_index_upload"): L.sg_index_upload.argtypes = [vp, i32]
+    if hasattr(L, "sg_index_replicate"): L.sg_index_replicate.argtypes = [vp, vp, u32]
+    if hasattr(L, "sg_index_tune"): L.sg_index_tune.argtypes = [vp, C.c_char_p, i32]
+    if hasattr(L, "sg_index_forward"): L.sg_index_forward.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+    if hasattr(L, "sg_index_replicas"): L.sg_index_replicas.argtypes = [vp, vp, u32]
+    if hasattr(L, "sg_index_replicas"): L.sg_index_replicas.restype = u32
+    if hasattr(L, "sg_suggest_batch"): L.sg_suggest_batch.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
+    if hasattr(L, "sg_suggest_batch_multi"): L.sg_suggest_batch_multi.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp]
+    if hasattr(L, "sg_autocomplete_batch_multi"): L.sg_autocomplete_batch_multi.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    if hasattr(L, "sg_suggest_one"): L.sg_suggest_one.argtypes = [vp, C.c_char_p, u32, i32, dbl, u32, vp, vp, vp]
+    if hasattr(L, "sg_autocomplete_one"): L.sg_autocomplete_one.argtypes = [vp, C.c_char_p, u32, u32, vp, vp]
+    if hasattr(L, "sg_suggest_batch_device"): L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
+    if hasattr(L, "sg_autocomplete_batch"): L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    if hasattr(L, "sg_autocomplete_batch_device"): L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+    if hasattr(L, "sg_lm_load_google"): L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    if hasattr(L, "sg_lm_load_google_ex"): L.sg_lm_load_google_ex.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp)]
+    if hasattr(L, "sg_lm_load_binary"): L.sg_lm_load_binary.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    if hasattr(L, "sg_lm_level"): L.sg_lm_level.argtypes = [vp, u32, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    if hasattr(L, "sg_lm_order"): L.sg_lm_order.argtypes = [vp]
+    if hasattr(L, "sg_lm_order"): L.sg_lm_order.restype = u32
+    if hasattr(L, "sg_lm_build_google"): L.sg_lm_build_google.argtypes = [C.c_char_p, u64, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p]
+    if hasattr(L, "sg_lm_retain"): L.sg_lm_retain.argtypes = [vp]
+    if hasattr(L, "sg_lm_retain"): L.sg_lm_retain.restype = None
+    if hasattr(L, "sg_lm_release"): L.sg_lm_release.argtypes = [vp]
+    if hasattr(L, "sg_lm_release"): L.sg_lm_release.restype = None
+    if hasattr(L, "sg_lm_num_words"): L.sg_lm_num_words.argtypes = [vp]
+    if hasattr(L, "sg_lm_num_words"): L.sg_lm_num_words.restype = u32
+    if hasattr(L, "sg_lm_word"): L.sg_lm_word.argtypes = [vp, u32, C.c_char_p, u32]
+    if hasattr(L, "sg_lm_word_id"): L.sg_lm_word_id.argtypes = [vp, C.c_char_p, u32]
+    if hasattr(L, "sg_lm_word_id"): L.sg_lm_word_id.restype = u32
+    for f in (L.sg_lm_score, L.sg_lm_score_word_ids):  # noqa
         f.argtypes = [vp, vp, u32]
         f.restype = dbl
-    L.sg_lm_next_score.argtypes = [vp, vp, u32, u32, i32, C.POINTER(dbl)]
-    L.sg_lm_tokenize.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32]
-    L.sg_spell_index_build.argtypes = [vp, C.POINTER(SgDesc), i32, C.POINTER(vp)]
-    L.sg_spell_predict_batch.argtypes = [vp, vp, vp, vp, u32, u32, dbl, vp, vp]
-    L.sg_index_retain.argtypes = [vp]
-    L.sg_index_retain.restype = None
-    L.sg_index_release.argtypes = [vp]
-    L.sg_index_release.restype = None
-    L.sg_last_error.restype = C.c_char_p
-    L.sg_index_stats.argtypes = [vp, C.POINTER(SgStats)]
-    L.sg_tokenize.argtypes = [vp, C.c_char_p, u32, i32, vp, u32]
-    L.sg_term_string.argtypes = [vp, u64, C.c_char_p, u32]
-    L.sg_index_list.argtypes = [vp, u32, u64, vp, u64, C.POINTER(u64)]
-    L.sg_index_list.restype = C.c_int64
-    L.sg_index_lists.argtypes = [vp, vp, vp, u64]
-    L.sg_index_lists.restype = u64
-    L.sg_suggest_algorithmic_bytes.argtypes = [vp, vp, vp, u32, i32, dbl, u32, C.POINTER(u64)]
+    if hasattr(L, "sg_lm_next_score"): L.sg_lm_next_score.argtypes = [vp, vp, u32, u32, i32, C.POINTER(dbl)]
+    if hasattr(L, "sg_lm_tokenize"): L.sg_lm_tokenize.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32]
+    if hasattr(L, "sg_spell_index_build"): L.sg_spell_index_build.argtypes = [vp, C.POINTER(SgDesc), i32, C.POINTER(vp)]
+    if hasattr(L, "sg_spell_predict_batch"): L.sg_spell_predict_batch.argtypes = [vp, vp, vp, vp, u32, u32, dbl, vp, vp]
+    if hasattr(L, "sg_index_retain"): L.sg_index_retain.argtypes = [vp]
+    if hasattr(L, "sg_index_retain"): L.sg_index_retain.restype = None
+    if hasattr(L, "sg_index_release"): L.sg_index_release.argtypes = [vp]
+    if hasattr(L, "sg_index_release"): L.sg_index_release.restype = None
+    if hasattr(L, "sg_last_error"): L.sg_last_error.restype = C.c_char_p
+    if hasattr(L, "sg_index_stats"): L.sg_index_stats.argtypes = [vp, C.POINTER(SgStats)]
+    if hasattr(L, "sg_tokenize"): L.sg_tokenize.argtypes = [vp, C.c_char_p, u32, i32, vp, u32]
+    if hasattr(L, "sg_term_string"): L.sg_term_string.argtypes = [vp, u64, C.c_char_p, u32]
+    if hasattr(L, "sg_index_list"): L.sg_index_list.argtypes = [vp, u32, u64, vp, u64, C.POINTER(u64)]
+    if hasattr(L, "sg_index_list"): L.sg_index_list.restype = C.c_int64
+    if hasattr(L, "sg_index_lists"): L.sg_index_lists.argtypes = [vp, vp, vp, u64]
+    if hasattr(L, "sg_index_lists"): L.sg_index_lists.restype = u64
+    if hasattr(L, "sg_suggest_algorithmic_bytes"): L.sg_suggest_algorithmic_bytes.argtypes = [vp, vp, vp, u32, i32, dbl, u32, C.POINTER(u64)]
     _lib = L
     return L
 

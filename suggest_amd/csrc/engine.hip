@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -41,7 +42,9 @@ namespace sg {
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
 #define SG_ROWTAB_CAP 84      // row descriptors (8 B + 1 B) per streaming window
 #define SG_QH 192             // slots of the query-term hash (LDS): A <= 128 occurrences, load <= 0.67
-#define SG_CAND_BIG 128       // the candidate queue of launches whose top-k rows leave the room (k <= SG_K_BIGQ)
+#define SG_CAND_BIG 112       // the candidate queue of launches whose top-k rows leave the room (k <= SG_K_BIGQ)
+#define SG_EPOCHS 4           // group passes whose candidates may wait in the queue together (ring of their streamed-list masks + docID ranges)
+#define SG_EPOCH_WORDS 6
 #define SG_K_BIGQ 21
 #define SG_MAX_PARTS 32       // parts a heavy query is cut into
 
@@ -765,8 +768,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // candidates are emitted — and rebuilds the hash afterwards
   uint32_t* dup_scratch = rowtab;
   static_assert(SG_DUP_SCRATCH <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64 + SG_QH + SG_QH / 4,
-                "dup scratch must fit row table + dummies + hash");
-  uint32_t* tk_id_lds = qh_key + SG_QH + SG_QH / 4; // top-k rows: min(k, SG_K_LDS) ids, then as many 64-bit scores
+                "dup scratch must fit row table + dummies + hash");   // (the epoch ring behind the hash is NOT part of it)
+  uint32_t* ep_ring = qh_key + SG_QH + SG_QH / 4;   // [SG_EPOCHS][6] streamed-list mask (128 bits over query positions) + docID range of a group pass
+  uint32_t* tk_id_lds = ep_ring + SG_EPOCH_WORDS * SG_EPOCHS;    // top-k rows: min(k, SG_K_LDS) ids, then as many 64-bit scores
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + ((min(a.k, (uint32_t)SG_K_LDS) + 1u) & ~1u));
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
@@ -927,8 +931,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // ---- candidate queue: docs whose bucket reached the flag threshold wait here (with the query position of the list
     //      they were met in) and are verified together at the end of their group — or earlier when the queue fills ----
     uint32_t qn = 0;
+    uint32_t epoch = 0, flushed_at = 0;                         // running group number; its value at the last flush
     uint64_t str_m[2] = {0, 0};                                 // query positions whose list the current group streams
-    uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;                  // docID range of the current pass
+    uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;                  // docID range of the current pass (whole range outside pass groups)
     auto offer = [&](uint32_t d, int overlap, int w) {
       if (kLM)                                                              // lmCollector: score = ScoreNext(doc), monotone in the count
         topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
@@ -985,15 +990,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // streamed list that holds it (bucket counts only grow, so that occurrence is always flagged): `later` = some streamed
     // query position behind the one it was met in holds one of its terms.  No dedup set, no bound on candidates per group.
     auto flush_queue = [&]() {
+      flushed_at = epoch;
       if (qn == 0) return;
       PH(2)
       __syncthreads();
       for (uint32_t base = 0; base < qn; base += 64) {          // 64 candidates (one per lane for the record loads) at a time
-      const uint32_t n = min(64u, qn - base);
+      uint32_t n = min(64u, qn - base);
       uint32_t* qd = cq_doc + base;
       uint32_t* qj = cq_jj + base;
-      const uint32_t my_doc = (uint32_t)lane < n ? qd[lane] : 0u;
-      const uint32_t my_jj = (uint32_t)lane < n ? qj[lane] : 0u;
+      uint32_t my_doc = (uint32_t)lane < n ? qd[lane] : 0u;
+      uint32_t my_jj = (uint32_t)lane < n ? qj[lane] : 0u;
+      if (n >= 8u) {
+        // A matching document is queued once per list that flagged it (dictionaries of near-duplicates: dozens of times).
+        // Of the entries of one document in this batch only the one met in the LAST list can be its last occurrence — the
+        // others are "late" by the mere presence of that one, and go without a single load.  128-slot table in the row
+        // table's LDS (idle outside the stream): max over (doc, list) per slot; a slot two documents share favours the
+        // larger docID, the other is simply verified as usual.
+        unsigned long long* dh = (unsigned long long*)rowtab;
+        static_assert(2 * 128 <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64, "dedup table must fit row table + dummies");
+        dh[lane] = 0ull; dh[64 + lane] = 0ull;
+        __syncthreads();
+        const uint32_t slot = (my_doc * 0x9E3779B1u) >> 25;
+        const unsigned long long mine = ((unsigned long long)my_doc << 32) | (unsigned long long)(my_jj & 0xFFu);
+        if ((uint32_t)lane < n) __hip_atomic_fetch_max(dh + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        const unsigned long long top = dh[slot];
+        const bool alive = (uint32_t)lane < n && !((uint32_t)(top >> 32) == my_doc && (uint32_t)top > (my_jj & 0xFFu));
+        const uint64_t am = ballot(alive);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+        __syncthreads();
+        if (alive) { qd[rank] = my_doc; qj[rank] = my_jj; }
+        __syncthreads();
+        n = popc64(am);
+        my_doc = (uint32_t)lane < n ? qd[lane] : 0u;
+        my_jj = (uint32_t)lane < n ? qj[lane] : 0u;
+      }
       uint2 rec = make_uint2(0u, 0u);
       if ((uint32_t)lane < n) rec = ix.fwd_rec[my_doc];
       uint32_t nd_max = rec.y >> 16;
@@ -1002,66 +1033,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const int gsz = nd_max <= 8u ? 8 : nd_max <= 16u ? 16 : nd_max <= 32u ? 32 : 64, ngrp = 64 / gsz;
       const int gi = lane / gsz, ti = lane - gi * gsz;
       const uint64_t gmask = gsz == 64 ? ~0ull : ((1ull << gsz) - 1ull) << (gi * gsz);
-      for (uint32_t c0 = 0; c0 < n; c0 += 4u * (uint32_t)ngrp) {
-        uint32_t cc[4], c_off[4], c_nd[4], c_jj[4];
-        int ov[4] = {0, 0, 0, 0};
-        bool late[4] = {false, false, false, false};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          cc[j] = c0 + (uint32_t)(j * ngrp + gi);
-          const int src = (int)(min(cc[j], 63u) << 2);           // every lane takes part in the permutes
-          // (ds_bpermute returns 0 from a source lane that is switched off: the permutes must not end up under a branch —
-          //  a candidate's record lives in lane cc[j], which may belong to a lane group with nothing to do this round)
-          c_off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.x);
-          const uint32_t ry = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.y);
-          c_jj[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)my_jj);
-          asm volatile("" : "+v"(c_off[j]), "+v"(c_jj[j]) : "v"(ry));      // pin the three permutes here, unpredicated
-          c_nd[j] = cc[j] < n ? ry >> 16 : 0u;
-        }
-        for (uint32_t s0 = 0; s0 < nd_max; s0 += (uint32_t)gsz) {   // one round unless a document has more than 64 distinct terms
-          uint32_t x[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint32_t slot = s0 + (uint32_t)ti;
-            x[j] = slot < c_nd[j] ? ix.fwd_terms[(uint64_t)c_off[j] * 4u + slot] : kNoTerm;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            uint32_t mult = 0;
-            bool lt = false;
-            if (x[j] != kNoTerm) {
-              for (uint32_t h = d_qhash(x[j]);; h = d_qnext(h)) {
-                const uint32_t kx = qh_key[h];
-                if (kx == kNoTerm) break;
-                if (kx == x[j]) {
-                  const uint32_t pp = qh_pos[h];
-                  mult++;
-                  lt |= pp > c_jj[j] && (((pp < 64u ? str_m[0] : str_m[1]) >> (pp & 63u)) & 1ull);
-                }
+      // one candidate per lane group and iteration; the next iteration's term loads are issued before this one's are used
+      auto fetch_terms = [&](uint32_t c0, uint32_t s0, uint32_t& x_off, uint32_t& x_nd, uint32_t& x_jj) -> uint32_t {
+        const uint32_t cc = c0 + (uint32_t)gi;
+        const int src = (int)(min(cc, 63u) << 2);
+        // (ds_bpermute returns 0 from a source lane that is switched off: the permutes must not end up under a branch —
+        //  a candidate's record lives in lane cc, which may belong to a lane group with nothing to do this round)
+        x_off = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.x);
+        const uint32_t ry = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.y);
+        x_jj = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)my_jj);
+        asm volatile("" : "+v"(x_off), "+v"(x_jj) : "v"(ry));      // pin the three permutes here, unpredicated
+        x_nd = cc < n ? ry >> 16 : 0u;
+        const uint32_t slot = s0 + (uint32_t)ti;
+        return slot < x_nd ? ix.fwd_terms[(uint64_t)x_off * 4u + slot] : kNoTerm;
+      };
+      const uint32_t rounds = (nd_max + (uint32_t)gsz - 1u) / (uint32_t)gsz;   // 1 unless a document has more than 64 distinct terms
+      uint32_t n_off, n_nd, n_jj;
+      uint32_t x_next = fetch_terms(0u, 0u, n_off, n_nd, n_jj);
+      for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)ngrp) {
+        int ov = 0;
+        bool late = false;
+        const uint32_t cc = c0 + (uint32_t)gi;
+        for (uint32_t rd = 0; rd < rounds; rd++) {
+          const uint32_t x = x_next, c_jj = n_jj & 0xFFu, c_ep = (n_jj >> 8) & (SG_EPOCHS - 1u);
+          const bool last_rd = rd + 1u == rounds;
+          if (!last_rd || c0 + (uint32_t)ngrp < n) x_next = fetch_terms(last_rd ? c0 + (uint32_t)ngrp : c0, last_rd ? 0u : (rd + 1u) * (uint32_t)gsz, n_off, n_nd, n_jj);
+          uint32_t mult = 0;
+          bool lt = false;
+          if (x != kNoTerm) {
+            for (uint32_t h = d_qhash(x);; h = d_qnext(h)) {
+              const uint32_t kx = qh_key[h];
+              if (kx == kNoTerm) break;
+              if (kx == x) {
+                const uint32_t pp = qh_pos[h];
+                mult++;
+                lt |= pp > c_jj && ((ep_ring[c_ep * SG_EPOCH_WORDS + (pp >> 5)] >> (pp & 31u)) & 1u);
               }
             }
-            const uint64_t mm = ballot(mult != 0u);
-            ov[j] += (int)popc64(mm & gmask);
-            uint64_t m2 = ballot(mult > 1u);                     // a query that repeats a term: the extra occurrences
-            while (m2) {
-              const int l = __builtin_ctzll(m2);
-              m2 &= m2 - 1;
-              const uint32_t extra = readlane(mult, l) - 1u;
-              if (l / gsz == gi) ov[j] += (int)extra;
-            }
-            late[j] |= (ballot(lt) & gmask) != 0ull;
           }
+          const uint64_t mm = ballot(mult != 0u);
+          ov += (int)popc64(mm & gmask);
+          uint64_t m2 = ballot(mult > 1u);                       // a query that repeats a term: the extra occurrences
+          while (m2) {
+            const int l = __builtin_ctzll(m2);
+            m2 &= m2 - 1;
+            const uint32_t extra = readlane(mult, l) - 1u;
+            if (l / gsz == gi) ov += (int)extra;
+          }
+          late |= (ballot(lt) & gmask) != 0ull;
         }
-        // verdict into the queue slot (consumed): bit 31 = emit, bits 8..23 cardinality, bits 0..7 overlap
-        if (ti == 0) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (cc[j] < n) {
-              const uint32_t dd = qd[cc[j]];
-              const bool keep = !late[j] && dd >= lo_doc && dd < hi_doc;
-              qj[cc[j]] = keep ? (0x80000000u | (uint32_t)ov[j]) : 0u;
-            }
-          }
+        // verdict into the queue slot (consumed): bit 31 = emit, bits 0..7 overlap
+        if (ti == 0 && cc < n) {
+          const uint32_t dd = qd[cc], v_ep = (qj[cc] >> 8) & (SG_EPOCHS - 1u);      // (its pass's docID range: a document on a
+          const bool keep = !late && dd >= ep_ring[v_ep * SG_EPOCH_WORDS + 4u] && dd < ep_ring[v_ep * SG_EPOCH_WORDS + 5u];   // pass boundary is met twice)
+          qj[cc] = keep ? (0x80000000u | (uint32_t)ov) : 0u;
         }
       }
       __syncthreads();
@@ -1165,9 +1190,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       DBG_COUNT(0, 1)
       bool saturated = false, overflow = false;
-      // the group's streamed lists as a mask over query positions (what `later` in flush_queue is asked against)
+      // the group's streamed lists as a mask over query positions (what `later` in flush_queue is asked against); candidates
+      // wait in the queue across groups — up to SG_EPOCHS of them — so the masks of the recent groups are kept in a ring
       str_m[0] = ballot(ln_r[0] != 0u) & ~skip_m[0];
       str_m[1] = a_rounds > 1 ? ballot(ln_r[1] != 0u) & ~skip_m[1] : 0ull;
+      uint32_t ep_tag = 0, q0 = qn;                             // (set at the top of every pass)
       // slow path of one counted batch whose row descriptors are rows4[0..3]: the flagged postings go to the queue
       // (per posting slot one ballot + a prefix count: the lanes store their own postings)
       auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
@@ -1189,11 +1216,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           if (ballot(hot != 0)) saturated = true;
         }
         if (overflow) return;                                    // (the saturation watch above goes on)
-#pragma nounroll
-        for (int ue = 0; ue < 4 * SG_UNROLL; ue++) {             // (vv[ue]: a uniform dynamic index into the register vector)
+        uint32_t any_fl = fl;                                    // OR over the wave: the posting slots flagged in any lane
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) any_fl |= (uint32_t)__shfl_xor((int)any_fl, off, 64);
+        any_fl = __builtin_amdgcn_readfirstlane(any_fl);
+        while (any_fl) {                                         // (vv[ue]: a uniform dynamic index into the register vector)
+          const int ue = __builtin_ctz(any_fl);
+          any_fl &= any_fl - 1u;
           const bool mine = (fl >> ue) & 1u;
           const uint64_t m = ballot(mine);
-          if (!m) continue;
           const uint32_t cnt_f = popc64(m);
           DBG_COUNT(2, cnt_f)
           // a full queue is not emptied here (verification in the middle of the stream loop costs the loop its registers):
@@ -1201,7 +1232,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           if (qn + cnt_f > cq_cap || DBG_SKIP(1024u)) { overflow = true; break; }
           DBG_COUNT(3, cnt_f)
           const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = rowlist[row0 + (uint32_t)(ue >> 2)]; }
+          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = (uint32_t)rowlist[row0 + (uint32_t)(ue >> 2)] | ep_tag; }
           qn += cnt_f;
         }
       };
@@ -1216,7 +1247,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
       uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
       uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
-      lo_doc = 0; hi_doc = 0xFFFFFFFFu;
+      const bool last_group = wnext >= Wt || (vmask >> wnext) == 0ull;
       for (uint32_t pass = 0; pass < n_pass; pass++) {
       DBG_COUNT(4, 1)
       if (n_pass > 1) {
@@ -1290,6 +1321,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       // ---- streaming passes: normally one; a saturated u8 pass is repeated with u32 counters ----
       saturated = false; overflow = false;
+      // this pass's slot in the epoch ring (the flush at the end of the previous pass made sure it is free)
+      epoch++;
+      ep_tag = (epoch & (SG_EPOCHS - 1u)) << 8;
+      q0 = qn;                                                  // the queue below q0 belongs to earlier passes / groups
+      if (lane == 0) {
+        uint32_t* er = ep_ring + (epoch & (SG_EPOCHS - 1u)) * SG_EPOCH_WORDS;
+        er[0] = (uint32_t)str_m[0]; er[1] = (uint32_t)(str_m[0] >> 32); er[2] = (uint32_t)str_m[1]; er[3] = (uint32_t)(str_m[1] >> 32);
+        er[4] = lo_doc; er[5] = hi_doc;
+      }
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
         for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
@@ -1376,7 +1416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (!(u8 && saturated)) break;
         // A u8 counter came close to wrapping: the group is counted again with u32 counters (nothing of it has reached
         // the top-k yet: its candidates are only queued)
-        qn = 0; overflow = false;
+        qn = q0; overflow = false;
         u8 = false; saturated = false;
         lg = min(lg, a.log2_cnt);
         __syncthreads();
@@ -1386,11 +1426,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // flagged in every list from its T'-th on).  The lists are walked again against the FINAL counters — a superset of
         // what the stream flagged, counts only grow — and the queue is emptied whenever it fills; the verdict rule (emit at
         // the last streamed list holding the doc) keeps every document single.
-        qn = 0;
-        __syncthreads();
+        qn = q0;                                                 // this pass's entries go (what earlier ones queued stays)
+        int lists_before = 0;
         for (int i = 0; i < A; i++) {
           const int r = (i >> 6) & 1, li = i & 63;
           if (!(((r ? str_m[1] : str_m[0]) >> li) & 1ull)) continue;
+          // a document in >= Teff streamed lists has its LAST occurrence in the Teff-th streamed list or later
+          if (lists_before++ < Teff - 1) continue;
           const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li);
           for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t c = c0 + lane;
@@ -1412,14 +1454,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
               DBG_COUNT(3, cnt_f)
               if (qn + cnt_f > cq_cap) flush_queue();
               const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-              if (flag) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i; }
+              if (flag) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i | ep_tag; }
               qn += cnt_f;
             }
           }
         }
       }
-      flush_queue();                                            // this pass's candidates (they are judged against its lists and range)
+      // candidates wait across passes and groups (one verification of many instead of many of few); they are verified
+      // when the next pass would reuse a live ring slot, when the queue is half full, and before the tile's segment table goes
+      if (epoch + 1u - flushed_at >= SG_EPOCHS || qn > cq_cap / 2 || (last_group && pass + 1u == n_pass)) flush_queue();
       }  // docID-range passes
+      lo_doc = 0; hi_doc = 0xFFFFFFFFu;
     }
   }
 

@@ -138,7 +138,7 @@ static bool read_cdb_words(const char* path, std::vector<std::string>& words, st
   auto u32 = [&](size_t o) { return (uint32_t)(uint8_t)d[o] | ((uint32_t)(uint8_t)d[o + 1] << 8) | ((uint32_t)(uint8_t)d[o + 2] << 16) | ((uint32_t)(uint8_t)d[o + 3] << 24); };
   if (d.size() < 2048) { err = "cdb dictionary is truncated"; return false; }
   size_t end = d.size();
-  for (int i = 0; i < 256; i++) end = std::min<size_t>(end, u32((size_t)i * 8));
+  for (int i = 0; i < 256; i++) if (u32((size_t)i * 8 + 4)) end = std::min<size_t>(end, u32((size_t)i * 8));   // (an empty table has no position)
   std::map<uint32_t, std::string> by_id;
   for (size_t pos = 2048; pos + 8 <= end;) {
     const size_t klen = u32(pos), dlen = u32(pos + 4);

@@ -57,7 +57,8 @@ def read_cdb_dictionary(path):
         data = f.read()
     if len(data) < 2048:
         raise IOError("failed to open cdb dictionary file: %s" % path)
-    end = min(struct.unpack_from("<I", data, 8 * i)[0] for i in range(256))
+    tables = [struct.unpack_from("<II", data, 8 * i) for i in range(256)]
+    end = min([pos for pos, n in tables if n] or [len(data)])            # (an empty table carries no position)
     out = {}
     pos = 2048
     while pos < end:

@@ -56,6 +56,13 @@ def lib():
         L.or_query_algorithmic_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int]
         L.or_lm_load.restype = C.c_void_p
         L.or_lm_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.or_lm_load_ex.restype = C.c_void_p
+        L.or_lm_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.or_lm_load_binary.restype = C.c_void_p
+        L.or_lm_load_binary.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.or_lm_level.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64)),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.or_lm_order.argtypes = [C.c_void_p]
         L.or_lm_free.argtypes = [C.c_void_p]
         L.or_lm_build_google.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.or_lm_words.restype = C.c_uint32
@@ -266,11 +273,30 @@ class OracleLM:
     """or_lm_*: the language model of the spellchecker caller (pkg/lm), loaded from Google-format n-gram count files
     <dir>/{1..order}-gm; word ids = line numbers of 1-gm."""
 
-    def __init__(self, directory, order, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-.")):
+    def __init__(self, directory=None, order=3, start_symbol="<S>", end_symbol="</S>", alphabet=("english", "russian", "numbers", "-."),
+                 id_order="lines", binary=None, dictionary=None):
+        """id_order "lines": word ids = 1-gm line numbers (the reference's test indexer); "count": (count desc, word asc) like
+        buildDictionary (binary.go:101-199).  binary + dictionary: RetrieveLMFromBinary from <name>.lm / <name>.cdb."""
         err = C.create_string_buffer(256)
-        self._h = lib().or_lm_load(_b(directory), int(order), _b(start_symbol), _b(end_symbol), b"\n".join(_b(a) for a in alphabet), err, 256)
+        alpha = b"\n".join(_b(a) for a in alphabet)
+        if binary is not None:
+            self._h = lib().or_lm_load_binary(_b(binary), _b(dictionary), _b(start_symbol), _b(end_symbol), alpha, err, 256)
+        else:
+            self._h = lib().or_lm_load_ex(_b(directory), int(order), _b(start_symbol), _b(end_symbol), alpha, {"lines": 0, "count": 1}[id_order], err, 256)
         if not self._h:
             raise IOError(err.value.decode())
+
+    def level(self, i):
+        """-> (containers u64[], values u64[], total) of level i, as packedArray.Store writes them"""
+        c, v = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        nc, nv, tot = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert lib().or_lm_level(self._h, i, C.byref(c), C.byref(nc), C.byref(v), C.byref(nv), C.byref(tot)) == 0
+        return (np.ctypeslib.as_array(c, shape=(nc.value,)).copy() if nc.value else np.zeros(0, np.uint64),
+                np.ctypeslib.as_array(v, shape=(nv.value,)).copy() if nv.value else np.zeros(0, np.uint64), int(tot.value))
+
+    @property
+    def order(self):
+        return int(lib().or_lm_order(self._h))
 
     def __del__(self):
         try:

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from suggest_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "suggest_amd", "libsuggest_hip_prof.so")
+_lib.LIB_PATH = os.path.join(ROOT, "suggest_amd", os.environ.get("SG_PROF_LIB", "libsuggest_hip_prof.so"))
 from suggest_amd import IndexDescription, NGramIndex, synth
 
 ap = argparse.ArgumentParser()
