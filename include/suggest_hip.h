@@ -129,7 +129,7 @@ int sg_autocomplete_batch_multi(sg_index* index, const uint8_t* q_utf8, const ui
 
 /* Suggester.Suggest / Autocomplete.Autocomplete as the reference calls them: ONE query per call, from many goroutines at
  * once (pkg/suggest/suggester.go:46, autocomplete.go:40, service_test.go:36-79).  Blocking; concurrent callers are
- * coalesced: the request is queued and dispatcher threads (SG_COALESCE_LANES per replica, default 2) run whatever is
+ * coalesced: the request is queued and dispatcher threads (SG_COALESCE_LANES per replica, default 1) run whatever is
  * pending with the same (metric, similarity, k) as one launch — no timer, an idle engine serves a lone request at once.
  * out_ids / out_scores hold k entries, *out_count the number written (or an SG_COUNT_* flag, nothing written). */
 int sg_suggest_one(sg_index* index, const uint8_t* q_utf8, uint32_t len, int metric, double similarity, uint32_t k,

@@ -63,7 +63,7 @@ def test_product_loads_and_builds_the_same_model(file_levels, reference_tests):
     ora = oracle.OracleLM(LM_DIR, 3, id_order="count")
     for m in (built, loaded):
         _same_levels(m, file_levels)
-        assert len(m) == 12 and [m.Find(i) for i in range(len(m))] == [w.decode() for w in ora.words()]
+        assert len(m) == 12 and [m.word(i) for i in range(len(m))] == ora.words()
     g = reference_tests["lm"]
     for sent, expected in g["score_sentence"]:
         assert abs(loaded.ScoreSentence(sent) - expected) < g["tolerance"], sent
