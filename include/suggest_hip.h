@@ -242,6 +242,10 @@ int sg_index_digest(const sg_index* index, uint64_t out[4]);
 int sg_suggest_algorithmic_bytes(const sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
                                  int metric, double similarity, uint32_t k, uint64_t* out_total);
 
+/* Same accounting for sg_autocomplete_batch: 4 * |postings| of every query term in every segment >= |terms| that holds them all. */
+int sg_autocomplete_algorithmic_bytes(const sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                                      uint32_t limit, uint64_t* out_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,9 @@ struct BatchArgs {
   const uint64_t* lm_values;   // word << 32 | count of every n-gram level, flattened; null: plain autocomplete
   const uint32_t* lm_from;     // [n_q] the continuations of query i's context are lm_values[lm_from[i] .. lm_to[i])
   const uint32_t* lm_to;       //       (sorted by word; from == to: no scorer, every candidate scores alike)
+  // a launch over a subset of the batch (the spellchecker's fuzzy top-up): workgroup b runs query q_sel[b], b < *q_sel_n
+  const uint32_t* q_sel;
+  const uint32_t* q_sel_n;
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -783,6 +786,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const bool splitting = a.split_ctl != nullptr;
   const bool primary = !kParts;
   uint32_t qi = blockIdx.x;
+  if (!kParts && a.q_sel) {
+    if (qi >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) return;
+    qi = __builtin_amdgcn_readfirstlane(a.q_sel[qi]);
+  }
   int r_lo = 0, r_hi = 0x7FFFFFFF;                      // segments this wavefront handles (a part of a split query)
   uint32_t my_slot = 0xFFFFFFFFu, my_part = 0;
   for (;;) {
@@ -1531,6 +1538,121 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// SpellChecker.Predict on the device (pkg/spellchecker/spellchecker.go:40-92), the steps around the two searches:
+//   spell_next_kernel    NGramModel.Next (ngram_model.go:64-98) for every query: the context's word ids are walked down the
+//                        levels (one binary search per level in the parent's bucket) to the range of its continuations
+//   spell_select_kernel  the queries whose completion list came back short get the fuzzy search (spellchecker.go:66-78)
+//   spell_merge_kernel   merge (unique), stable sort by ScoreNext (monotone in the continuation count), candidates[:topK+1] (sic)
+// ------------------------------------------------------------------------------------------
+struct SpellArgs {
+  const uint64_t* values;        // every level's (word << 32 | count), level after level
+  const uint32_t* child_begin;   // every level's bucket offsets, level after level
+  uint32_t level_base[8];        // first entry of level l in values
+  uint32_t cb_base[8];           // first entry of level l in child_begin
+  uint32_t n_parents[8];         // entries of level l - 1 (0 for the unigrams): the bucket of orphans is n_parents[l]
+  uint32_t order, n_q, top_k;
+  const uint32_t* ctx;           // [n_q][8] context word ids, already wrapped / trimmed like LanguageModel.Next
+  const uint8_t* ctx_len;        // [n_q] 0: no context (no scorer); 0xFF: the model's Next would return an error
+  const uint8_t* has_word;       // [n_q] the query has a last word to complete
+  uint32_t* lm_from; uint32_t* lm_to;   // [n_q] out: the continuations (absolute positions in values); from == to: none
+  uint8_t* status;               // [n_q] out: 0 scorer, 1 nil scorer, 2 error
+  const uint32_t* a_ids; const uint32_t* a_cnt;   // autocomplete rows [n_q][top_k]
+  const uint32_t* f_ids; const uint32_t* f_cnt;   // fuzzy rows [n_q][top_k] (rows of the selected queries only)
+  uint32_t* sel; uint32_t* sel_n;
+  uint32_t* out_ids; uint32_t* out_counts;        // [n_q][top_k + 1]
+};
+
+__global__ void spell_next_kernel(const SpellArgs p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_q) return;
+  const uint32_t n = p.ctx_len[i];
+  uint32_t from = 0, to = 0, st = 1;
+  if (n == 0xFFu) st = 2;                                     // "nGrams length should be less than the nGramModel order"
+  else if (n != 0u) {
+    uint32_t parent = kNoContext;
+    st = 0;
+    for (uint32_t l = 0; l < n && st == 0; l++) {
+      const uint32_t bucket = parent == kNoContext ? p.n_parents[l] : parent;
+      const uint32_t* cb = p.child_begin + p.cb_base[l];
+      uint32_t lo = cb[bucket], hi = cb[bucket + 1];
+      const uint32_t end = hi, w = p.ctx[(uint64_t)i * 8 + l];
+      const uint64_t* v = p.values + p.level_base[l];
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(v[mid] >> 32) < w) lo = mid + 1; else hi = mid; }
+      if (lo >= end || (uint32_t)(v[lo] >> 32) != w || (uint32_t)v[lo] == 0u) st = 1;   // unseen context: no scorer
+      parent = lo;
+    }
+    if (st == 0) {
+      const uint32_t* cb = p.child_begin + p.cb_base[n];
+      from = cb[parent]; to = cb[parent + 1];
+      if (from == to) st = 1;                                 // SubVector(parent) == nil
+      from += p.level_base[n]; to += p.level_base[n];
+    }
+  }
+  if (st) { from = 0; to = 0; }
+  p.lm_from[i] = from; p.lm_to[i] = to; p.status[i] = (uint8_t)st;
+}
+
+__global__ void spell_select_kernel(const SpellArgs p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_q) return;
+  const uint32_t c = p.a_cnt[i];
+  if (p.has_word[i] && c != SG_COUNT_TOO_LONG && c < p.top_k) p.sel[atomicAdd(p.sel_n, 1u)] = i;
+}
+
+// one wavefront per query: at most 2 * top_k candidates
+__global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
+  const uint32_t i = blockIdx.x, lane = threadIdx.x, k = p.top_k, row = k + 1u;
+  extern __shared__ uint32_t sm[];
+  uint32_t* cand = sm;                 // [2k]
+  uint32_t* cnt = sm + 2 * k;          // [2k] continuation counts
+  uint32_t* dst = sm + 4 * k;          // [2k] sorted
+  const uint32_t ac = p.a_cnt[i];
+  uint32_t out_c = 0xFFFFFFFFu;        // decided below
+  if (ac == SG_COUNT_TOO_LONG) out_c = SG_COUNT_TOO_LONG;
+  else if (!p.has_word[i]) out_c = 0u;
+  else if (p.status[i] == 2) out_c = SG_COUNT_LM_ERROR;
+  uint32_t n = 0;
+  if (out_c == 0xFFFFFFFFu) {
+    n = min(ac, k);
+    for (uint32_t j = lane; j < n; j += 64) cand[j] = p.a_ids[(uint64_t)i * k + j];
+    __syncthreads();
+    if (ac < k) {                                             // the fuzzy search ran for this query
+      const uint32_t fc = p.f_cnt[i];
+      if (fc >= SG_COUNT_TOO_LONG) out_c = fc;                // the reference panics / dead-locks here (suggester.go:62)
+      else {
+        for (uint32_t x = 0; x < min(fc, k); x++) {           // merge — spellchecker.go:133-150 (order of the fuzzy list kept)
+          const uint32_t y = p.f_ids[(uint64_t)i * k + x];
+          bool dup = false;
+          for (uint32_t j = lane; j < n; j += 64) dup |= cand[j] == y;
+          if (!__builtin_amdgcn_ballot_w64(dup)) { if (lane == 0) cand[n] = y; n++; }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if (out_c != 0xFFFFFFFFu) { if (lane == 0) p.out_counts[i] = out_c; return; }
+  const bool scorer = p.status[i] == 0;
+  if (scorer) {                                               // sort.SliceStable by ScoreNext desc — :127-131
+    const uint32_t from = p.lm_from[i], to = p.lm_to[i];
+    for (uint32_t j = 0; j < n; j++) {
+      const uint32_t c = d_lm_count(p.values, from, to, cand[j], (int)lane);
+      if (lane == 0) cnt[j] = c;
+    }
+    __syncthreads();
+    for (uint32_t j = lane; j < n; j += 64) {
+      uint32_t r = 0;
+      for (uint32_t x = 0; x < n; x++) r += (cnt[x] > cnt[j] || (cnt[x] == cnt[j] && x < j)) ? 1u : 0u;
+      dst[r] = cand[j];
+    }
+    __syncthreads();
+  }
+  const uint32_t* src = scorer ? dst : cand;
+  const uint32_t m = k < n ? row : n;                         // candidates[:topK+1] (sic) — :87-89
+  for (uint32_t j = lane; j < m; j += 64) p.out_ids[(uint64_t)i * row + j] = src[j];
+  if (lane == 0) p.out_counts[i] = m;
+}
 
 #define sg_search_kernel sg_search_kernel_t<false, false>
 #define sg_parts_kernel sg_search_kernel_t<true, false>
