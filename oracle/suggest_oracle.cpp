@@ -396,6 +396,16 @@ struct GoSort {
   }
 };
 
+// test hook: the permutation go_sort gives n keys (out[i] = original index of the element that ends at position i)
+extern "C" void or_go_sort(const uint32_t* keys, int n, uint32_t* out) {
+  std::vector<uint32_t> k(keys, keys + n);
+  for (int i = 0; i < n; i++) out[i] = (uint32_t)i;
+  GoSort g;
+  g.less = [&](int i, int j) { return k[i] < k[j]; };
+  g.swap = [&](int i, int j) { std::swap(k[i], k[j]); std::swap(out[i], out[j]); };
+  g.sort(n);
+}
+
 // sort.Sort(rid) with Rid.Less = Len() < Len() — list_merger.go:23-31
 static void sort_rid(std::vector<Iter>& rid, bool reverse = false) {
   GoSort g;

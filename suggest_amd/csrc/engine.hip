@@ -1654,6 +1654,19 @@ __global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
   if (lane == 0) p.out_counts[i] = m;
 }
 
+// test hook (sg_debug_pairsort): the device's restatement of Go 1.14 sort.Sort on arbitrary keys — a differential fuzz
+// compares it with the oracle's and with a third, independent restatement (tests/gosort.py)
+__global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys, uint32_t n, uint32_t* out_vals) {
+  __shared__ uint32_t k[SG_MAX_A], v[SG_MAX_A];
+  __shared__ int stk[64];
+  for (uint32_t i = threadIdx.x; i < n; i += 64) { k[i] = keys[i]; v[i] = i; }
+  __syncthreads();
+  PairSort ps{k, v, stk};
+  ps.sort((int)n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 64) out_vals[i] = v[i];
+}
+
 #define sg_search_kernel sg_search_kernel_t<false, false>
 #define sg_parts_kernel sg_search_kernel_t<true, false>
 #define sg_lm_kernel sg_search_kernel_t<false, true>

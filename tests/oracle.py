@@ -63,6 +63,7 @@ def lib():
         L.or_lm_level.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64)),
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.or_lm_order.argtypes = [C.c_void_p]
+        L.or_go_sort.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.or_lm_free.argtypes = [C.c_void_p]
         L.or_lm_build_google.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.or_lm_words.restype = C.c_uint32
@@ -350,3 +351,11 @@ class OracleLM:
         lib().or_spell_predict_batch(index._h, self._h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n, int(top_k),
                                      float(similarity), ids.ctypes.data, cnt.ctypes.data, threads or (os.cpu_count() or 1))
         return ids, cnt
+
+
+def go_sort(keys):
+    """the oracle's Go 1.14 sort.Sort restatement: permutation of the indices of `keys`"""
+    k = np.ascontiguousarray(keys, dtype=np.uint32)
+    out = np.zeros(len(k), dtype=np.uint32)
+    lib().or_go_sort(k.ctypes.data, len(k), out.ctypes.data)
+    return out.tolist()

@@ -149,3 +149,22 @@ def test_device_built_store_stays_resident_and_matches_host_build():
         b = host.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k)
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+def test_device_pairsort_matches_the_other_two_go_sort_restatements():
+    """differential fuzz of the device's Go 1.14 sort.Sort (PairSort, engine.hip) against the oracle's and tests/gosort.py"""
+    import ctypes as C
+    import random
+    import gosort
+    from suggest_amd import _lib
+    L = _lib.lib()
+    rng = random.Random(2014)
+    for trial in range(400):
+        n = rng.choice([1, 2, 5, 12, 13, 14, 30, 41, 60, 100, 128])
+        spread = rng.choice([1, 2, 3, 5, 17, 1000])
+        keys = np.array([rng.randrange(spread) for _ in range(n)], dtype=np.uint32)
+        if trial % 7 == 0:
+            keys.sort()
+        out = np.zeros(n, dtype=np.uint32)
+        _lib.check(L.sg_debug_pairsort(0, keys.ctypes.data, n, out.ctypes.data))
+        assert out.tolist() == gosort.go_sort(keys.tolist()) == oracle.go_sort(keys), (trial, keys.tolist())

@@ -181,3 +181,40 @@ def test_reference_crash_inputs_are_flagged(cars_index):
     assert cars_index.suggest(long_q, "jaccard", 0.5, 5) == oracle.STATUS_REFERENCE_PANICS
     # empty token list -> empty result, no error (suggester.go:49-51)
     assert cars_index.suggest("", "jaccard", 0.5, 5) == []
+
+
+def test_go_sort_three_restatements_agree():
+    """Go 1.14 sort.Sort orders EQUAL-length posting lists in cpMerge (cp_merge.go:24) — visible only in the secondary rows of
+    documents that repeat a term.  No Go toolchain here, so it stays parity-unpinned; what can be checked is that three
+    separately written restatements (oracle C++, tests/gosort.py, the device's PairSort — the latter in the GPU suite)
+    produce the same unstable order on inputs full of ties, through every branch (insertion < 13, ninther > 40, the
+    protected partition, heapsort on exhausted depth)."""
+    import random
+    import gosort
+    rng = random.Random(1914)
+    for trial in range(1500):
+        n = rng.choice([0, 1, 2, 5, 12, 13, 14, 30, 41, 60, 100, 128])
+        spread = rng.choice([1, 2, 3, 5, 17, 1000])
+        keys = [rng.randrange(spread) for _ in range(n)]
+        if trial % 7 == 0:
+            keys.sort()
+        if trial % 11 == 0:
+            keys.sort(reverse=True)
+        a, b = oracle.go_sort(keys), gosort.go_sort(keys)
+        assert a == b, (keys, a, b)
+        assert [keys[i] for i in a] == sorted(keys)
+
+
+def test_lowercase_tables_of_oracle_and_product_come_from_two_sources_and_agree():
+    """oracle/unicode_lower.inc is read off glibc's towlower (oracle/gen_unicode_lower_glibc.c), the product's off Python's
+    unicodedata (tools/gen_unicode_lower.py): same pairs, none newer than Unicode 12.0 (Go 1.14)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tabs = []
+    for rel in ("oracle/unicode_lower.inc", "suggest_amd/csrc/unicode_lower.inc"):
+        txt = open(os.path.join(root, rel)).read()
+        tabs.append({int(a, 16): int(b, 16) for a, b in re.findall(r"\{0x([0-9A-Fa-f]+),\s*0x([0-9A-Fa-f]+)\}", txt)})
+        assert "glibc" in txt.splitlines()[0] if rel.startswith("oracle") else "gen_unicode_lower.py" in txt.splitlines()[0]
+    assert tabs[0] == tabs[1] and len(tabs[0]) == 1364
+    assert tabs[0][0x130] == 0x69 and tabs[0][0x410] == 0x430
+    assert not any(c in tabs[0] for c in (0xA7C7, 0xA7C9, 0xA7F5, 0x2C2F, 0xA7C0, 0x10570))
