@@ -23,12 +23,13 @@ def make(directory, tokens=50_000_000, vocab=1_000_000, zipf=1.07, seed=7, verbo
     rng = np.random.Generator(np.random.PCG64(seed))
     log = (lambda *a: print("[lm]", *a, file=sys.stderr, flush=True)) if verbose else (lambda *a: None)
     # ---- vocabulary: distinct random strings of 3..12 letters
-    need = int(vocab * 1.05) + 16
+    need = int(vocab * 1.3) + 64                               # (short strings collide: oversample, then cut)
     ln = rng.integers(3, 13, size=need)
     chars = rng.integers(0, 26, size=(need, 12), dtype=np.uint8) + ord("a")
     chars[np.arange(12)[None, :] >= ln[:, None]] = 0
     raw = np.unique(np.ascontiguousarray(chars).view("S12").ravel())
     raw = raw[rng.permutation(len(raw))[:vocab]]
+    vocab = len(raw)
     raw = np.concatenate([raw, np.array([b"<S>", b"</S>"], dtype="S12")])
     V = vocab
     S_ID, E_ID = V, V + 1
