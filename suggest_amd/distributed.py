@@ -130,7 +130,11 @@ class DocShardedIndex:
         import torch
         import torch.distributed as dist
 
-        ids, sc, cnt = self.index.suggest_batch(blob=blob, offs=offs, metric=metric, similarity=similarity, k=k)
+        if self.doc_hi == self.doc_lo:     # an empty shard (more ranks than documents): it has nothing to add, and it must not
+            n_q = len(offs) - 1            # report the reference's panic for a window it cannot even see
+            ids, sc, cnt = np.zeros((n_q, k), np.uint32), np.zeros((n_q, k), np.float64), np.zeros(n_q, np.uint32)
+        else:
+            ids, sc, cnt = self.index.suggest_batch(blob=blob, offs=offs, metric=metric, similarity=similarity, k=k)
         dev = self._comm_device(self.device) if (self.world > 1 and dist.is_initialized()) else torch.device("cpu")
         t_ids = torch.from_numpy(ids.astype(np.int64) + self.doc_lo).to(dev)         # local docID -> dictionary docID
         t_sc = torch.from_numpy(sc).to(dev)

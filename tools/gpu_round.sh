@@ -8,7 +8,7 @@ for s in $STEPS; do
   case $s in
     tests) timeout 1500 python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.log 2>&1; tail -5 $O/${TAG}_pytest.log ;;
     prof) for c in headline cfg2 cfg3 cfg4; do timeout 900 bash tools/profile_config.sh $TAG $c; done ;;
-    fullpmc) for c in cfg3 cfg4; do timeout 1200 bash tools/pmc_run.sh ${TAG}_$c --config $c > $O/${TAG}_pmc_$c.txt 2>&1; tail -60 $O/${TAG}_pmc_$c.txt; done ;;
+    fullpmc) for c in headline cfg3 cfg4; do timeout 1200 bash tools/pmc_run.sh ${TAG}_$c --config $c --batches 1 > $O/${TAG}_pmc_$c.txt 2>&1; tail -40 $O/${TAG}_pmc_$c.txt; done ;;
     phases)
       (timeout 300 python tools/phase_timing.py --metric cosine --similarity 0.4 --topk 20; \
        timeout 300 python tools/phase_timing.py --ngram 2 --metric dice --similarity 0.5 --queries 16384; \
