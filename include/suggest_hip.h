@@ -216,6 +216,10 @@ int sg_index_stats(const sg_index* index, sg_stats* out);
 int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, uint32_t* out_card, uint32_t* out_n,
                      uint64_t* out_keys);
 
+/* Test hook: the permutation the device's restatement of Go 1.14 sort.Sort (it orders equal-length posting lists in
+ * cpMerge.Merge, cp_merge.go:24) gives n <= 128 keys; out[i] = original index of the element that ends at position i. */
+int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* out);
+
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
  * SG_FILTER_LEVEL, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
 int sg_index_tune(sg_index* index, const char* knob, int value);

@@ -36,7 +36,7 @@ struct Reader {
   int64_t gob_int() { uint64_t u = gob_uint(); return (u & 1) ? ~(int64_t)(u >> 1) : (int64_t)(u >> 1); }
   std::string gob_string() {
     uint64_t len = gob_uint();
-    if (!ok || i + len > n) { ok = false; return {}; }
+    if (!ok || len > n - i) { ok = false; return {}; }       // (no i + len: an untrusted length may wrap)
     std::string s((const char*)p + i, (size_t)len);
     i += len;
     return s;
@@ -51,6 +51,7 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
   fseek(f, 0, SEEK_END);
   long sz = ftell(f);
   fseek(f, 0, SEEK_SET);
+  if (sz < 0) { fclose(f); return false; }
   out.resize((size_t)sz);
   bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
   fclose(f);
@@ -61,8 +62,8 @@ bool parse_header(const std::vector<uint8_t>& buf, std::string& version, uint32_
   Reader r{buf.data(), buf.size()};
   while (r.ok && r.i < r.n) {
     uint64_t len = r.gob_uint();
+    if (!r.ok || len > r.n - r.i) return false;
     size_t end = r.i + (size_t)len;
-    if (!r.ok || end > r.n) return false;
     int64_t type_id = r.gob_int();
     if (type_id < 0) { r.i = end; continue; }            // type definition message
     int field = -1;
@@ -75,6 +76,7 @@ bool parse_header(const std::vector<uint8_t>& buf, std::string& version, uint32_
       else if (field == 1) indices = (uint32_t)r.gob_uint();
       else if (field == 2) {
         uint64_t cnt = r.gob_uint();
+        if (!r.ok || cnt > r.n - r.i) return false;            // every term description takes at least a byte
         terms.reserve((size_t)cnt);
         for (uint64_t k = 0; k < cnt && r.ok; k++) {
           TermDesc td;
@@ -165,7 +167,7 @@ bool decode_roaring(const uint8_t* b, size_t n, std::vector<uint32_t>& out) {
       if (i + 2 > n) return false;
       uint32_t nr = u16(i); i += 2;
       if (i + 4ull * nr > n) return false;
-      for (uint32_t r = 0; r < nr; r++) { uint32_t s = u16(i), l = u16(i + 2); i += 4; for (uint32_t v = s; v <= s + l; v++) out.push_back(base + v); }
+      for (uint32_t r = 0; r < nr; r++) { uint32_t s = u16(i), l = u16(i + 2); i += 4; for (uint32_t v = s; v <= std::min(s + l, 0xFFFFu); v++) out.push_back(base + v); }   // (a run stays inside its container)
     } else if (card > 4096) {
       if (i + 8192 > n) return false;
       for (uint32_t w = 0; w < 1024; w++) {
