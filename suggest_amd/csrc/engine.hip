@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       //      are ascending, so a range is one contiguous run of chunks per list (rounded outwards to whole
       //      chunks: every doc of the range is seen completely in its own pass). ----
       uint32_t n_pass = 1;
-      if (g0 == g1) { while (n_pass < 1024u && need > max_buckets * n_pass) n_pass <<= 1; }
+      if (g0 == g1 && need > max_buckets) n_pass = min(1024u, (need + max_buckets - 1u) / max_buckets);   // (as many as needed: a power of two wasted up to half)
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
       uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
       uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
@@ -1281,11 +1281,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             while (ballot(glo < ghi)) {
               uint32_t pos[8], sv[8];
               const uint32_t span = ghi - glo;
-              const uint32_t m = 2u + (step >> 1), base = glo + step > m ? glo + step - m : 0u;
+              // (the docIDs of a list are uniform: where the boundary falls in a list of n postings has a standard deviation
+              //  of sqrt(p(1-p)n) postings — under one sample of 64 for n < 10^4 — so eight CONSECUTIVE samples around the
+              //  prediction bracket it in one round trip almost always; a miss falls through to the 9-ary rounds)
+              const uint32_t base = glo + step > 3u ? glo + step - 3u : 0u;
 #pragma unroll
               for (int i = 0; i < 8; i++) {
                 uint32_t x = span <= 8u || (predict && step <= 6u) ? glo + (uint32_t)i
-                             : predict ? base + (2u * m * (uint32_t)i) / 7u : glo + (span * (uint32_t)(i + 1)) / 9u;
+                             : predict ? base + (uint32_t)i : glo + (span * (uint32_t)(i + 1)) / 9u;
                 pos[i] = min(max(x, glo), g_end);
                 sv[i] = ix.cut_sample[pos[i]];
               }
