@@ -385,12 +385,31 @@ class NGramIndex {
   sg_index* Handle() const { return h_; }
 
   // Suggester.Suggest — suggester.go:46-131 with newFuzzyCollectorManager(topK)
+  // One query per call, as the reference's callers do it from many goroutines: sg_suggest_one coalesces the concurrent
+  // callers of this handle into shared launches.
   std::vector<Candidate> Suggest(const std::string& query, double similarity, metric::Metric m, int topK) const {
-    return std::move(SuggestBatch({query}, similarity, m, topK)[0]);
+    const size_t k = (size_t)(topK > 0 ? topK : 0);
+    std::vector<uint32_t> ids(k ? k : 1);
+    std::vector<double> scores(k ? k : 1);
+    uint32_t count = 0;
+    Check(sg_suggest_one(h_, (const uint8_t*)query.data(), (uint32_t)query.size(), m.id, similarity, (uint32_t)k, ids.data(), scores.data(), &count));
+    if (count == SG_COUNT_REF_PANIC) throw Error("reference behaviour: panic: makechan: size out of range");
+    if (count == SG_COUNT_REF_DEADLOCK) throw Error("reference behaviour: deadlock (unbuffered channel, suggester.go:62)");
+    if (count == SG_COUNT_TOO_LONG) throw Error("query has more than SG_MAX_QUERY_TERMS n-grams");
+    std::vector<Candidate> out;
+    for (uint32_t j = 0; j < count; j++) out.push_back(Candidate{ids[j], scores[j]});
+    return out;
   }
   // Autocomplete.Autocomplete — autocomplete.go:40-77 with newFirstKCollectorManager(limit)
   std::vector<Candidate> Autocomplete(const std::string& query, int limit) const {
-    return std::move(AutocompleteBatch({query}, limit)[0]);
+    const size_t k = (size_t)(limit > 0 ? limit : 0);
+    std::vector<uint32_t> ids(k ? k : 1);
+    uint32_t count = 0;
+    Check(sg_autocomplete_one(h_, (const uint8_t*)query.data(), (uint32_t)query.size(), (uint32_t)k, ids.data(), &count));
+    if (count == SG_COUNT_TOO_LONG) throw Error("query has more than SG_MAX_QUERY_TERMS n-grams");
+    std::vector<Candidate> out;
+    for (uint32_t j = 0; j < count; j++) out.push_back(Candidate{ids[j], 0.0});   // collector.go:104-106 -> service.go:165
+    return out;
   }
 
   std::vector<std::vector<Candidate>> SuggestBatch(const std::vector<std::string>& queries, double similarity, metric::Metric m,

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsuggest_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SG_LIB_NAME", "libsuggest_hip.so"))   # (SG_LIB_NAME: A/B timing against another build)
 
 SG_COUNT_REF_PANIC = 0xFFFFFFFF
 SG_COUNT_REF_DEADLOCK = 0xFFFFFFFE
