@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 
 #include "sg_internal.h"
 
@@ -276,68 +278,145 @@ void build_term_table(HostIndex& ix) {
   }
 }
 
+// Runs fn(block) for block = 0 .. n-1 on n threads (block 0 on the caller's).
+template <class F>
+static void run_blocks(uint32_t n, F fn) {
+  std::vector<std::thread> th;
+  for (uint32_t b = 1; b < n; b++) th.emplace_back([&fn, b] { fn(b); });
+  fn(0);
+  for (auto& t : th) t.join();
+}
+
+// What one thread learns about its contiguous block of docs in pass 1.
+struct BuildBlock {
+  uint32_t d0 = 0, d1 = 0;
+  std::vector<uint64_t> keys;                        // local term id -> key, first-occurrence order
+  std::unordered_map<uint64_t, uint32_t> local_of;
+  std::vector<uint32_t> terms;                       // unique term ids per doc, concatenated (local, then global ids)
+  std::vector<uint64_t> off;                         // [d1 - d0 + 1] into terms
+  struct Dup { uint32_t doc, term, mult; };
+  std::vector<Dup> dups;
+  std::vector<uint32_t> to_global;
+  std::vector<uint32_t> cursor;                      // [nT * S]: counts of this block, then its write cursors
+  uint32_t max_card = 0;
+  uint64_t raw = 0;
+  bool bad_key = false;
+};
+
 int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, HostIndex& ix,
                      std::string& err) {
   int rc = init_description(desc, ix, err);
   if (rc) return rc;
   ix.n_docs = n_docs;
 
-  // pass 1: tokenise, intern terms, remember each doc's (de-duplicated) term ids and cardinality
-  std::vector<uint32_t> doc_terms;       // unique term ids per doc, concatenated
-  std::vector<uint64_t> doc_off(n_docs + 1, 0);
+  // Contiguous blocks of docs, one thread each (SG_BUILD_THREADS, default: the cores this process may run on, at most
+  // 32).  Every step below is arranged so that the result is the one the sequential build gives: term ids in
+  // first-occurrence order over ascending docIDs, lists ascending.
+  uint32_t n_thr = std::min<uint32_t>(32, std::max<uint32_t>(1, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("SG_BUILD_THREADS")) n_thr = (uint32_t)std::max(1, atoi(e));
+  n_thr = std::max<uint32_t>(1, std::min<uint32_t>(n_thr, n_docs / 4096 + 1));
+  std::vector<BuildBlock> blk(n_thr);
+  for (uint32_t b = 0; b < n_thr; b++) {
+    blk[b].d0 = (uint32_t)((uint64_t)n_docs * b / n_thr);
+    blk[b].d1 = (uint32_t)((uint64_t)n_docs * (b + 1) / n_thr);
+  }
   std::vector<uint32_t> doc_card(n_docs);
-  doc_terms.reserve((size_t)n_docs * 16);
-  std::vector<uint64_t> keys;
-  std::vector<uint32_t> tids;
-  uint32_t max_card = 0;
-  struct RawDup { uint32_t doc, term, mult; };
-  std::vector<RawDup> raw_dups;
-  ix.term_of.reserve(1 << 16);
-  for (uint32_t d = 0; d < n_docs; d++) {
-    if (!tokenize_keys(ix, utf8 + offs[d], (size_t)(offs[d + 1] - offs[d]), false, keys)) {
-      err = "a term does not fit the 8-symbol key"; return SG_E_UNSUPPORTED;
-    }
-    uint32_t card = (uint32_t)keys.size();
-    doc_card[d] = card;
-    max_card = std::max(max_card, card);
-    tids.clear();
-    for (uint64_t k : keys) {
-      auto it = ix.term_of.find(k);
-      uint32_t t;
-      if (it == ix.term_of.end()) { t = (uint32_t)ix.term_key.size(); ix.term_key.push_back(k); ix.term_of.emplace(k, t); }
-      else t = it->second;
-      tids.push_back(t);
-    }
-    ix.n_postings_raw += card;
-    // a doc may repeat a term after normalisation; the CSR keeps (term,doc) once
-    bool has_dup = false;
-    for (size_t i = 1; i < tids.size() && !has_dup; i++)
-      for (size_t j = 0; j < i; j++) if (tids[i] == tids[j]) { has_dup = true; break; }
-    if (has_dup) {
-      std::vector<uint32_t> sorted = tids;
-      std::sort(sorted.begin(), sorted.end());
+
+  // pass 1: tokenise, intern terms per block, remember each doc's (de-duplicated) term ids and cardinality
+  run_blocks(n_thr, [&](uint32_t b) {
+    BuildBlock& B = blk[b];
+    B.off.assign((size_t)(B.d1 - B.d0) + 1, 0);
+    B.terms.reserve((size_t)(B.d1 - B.d0) * 16);
+    B.local_of.reserve(1 << 16);
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> tids, sorted;
+    for (uint32_t d = B.d0; d < B.d1; d++) {
+      if (!tokenize_keys(ix, utf8 + offs[d], (size_t)(offs[d + 1] - offs[d]), false, keys)) { B.bad_key = true; return; }
+      const uint32_t card = (uint32_t)keys.size();
+      doc_card[d] = card;
+      B.max_card = std::max(B.max_card, card);
+      B.raw += card;
       tids.clear();
-      for (size_t i = 0; i < sorted.size();) {
-        size_t j = i;
-        while (j < sorted.size() && sorted[j] == sorted[i]) j++;
-        tids.push_back(sorted[i]);
-        if (j - i > 1) raw_dups.push_back(RawDup{d, sorted[i], (uint32_t)(j - i)});
-        i = j;
+      for (uint64_t k : keys) {
+        auto it = B.local_of.find(k);
+        uint32_t t;
+        if (it == B.local_of.end()) { t = (uint32_t)B.keys.size(); B.keys.push_back(k); B.local_of.emplace(k, t); }
+        else t = it->second;
+        tids.push_back(t);
       }
+      // a doc may repeat a term after normalisation; the CSR keeps (term,doc) once
+      bool has_dup = false;
+      for (size_t i = 1; i < tids.size() && !has_dup; i++)
+        for (size_t j = 0; j < i; j++) if (tids[i] == tids[j]) { has_dup = true; break; }
+      if (has_dup) {
+        sorted = tids;
+        std::sort(sorted.begin(), sorted.end());
+        tids.clear();
+        for (size_t i = 0; i < sorted.size();) {
+          size_t j = i;
+          while (j < sorted.size() && sorted[j] == sorted[i]) j++;
+          tids.push_back(sorted[i]);
+          if (j - i > 1) B.dups.push_back(BuildBlock::Dup{d, sorted[i], (uint32_t)(j - i)});
+          i = j;
+        }
+      }
+      B.terms.insert(B.terms.end(), tids.begin(), tids.end());
+      B.off[d - B.d0 + 1] = B.terms.size();
     }
-    doc_terms.insert(doc_terms.end(), tids.begin(), tids.end());
-    doc_off[d + 1] = doc_terms.size();
+  });
+  uint32_t max_card = 0;
+  for (auto& B : blk) {
+    if (B.bad_key) { err = "a term does not fit the 8-symbol key"; return SG_E_UNSUPPORTED; }
+    max_card = std::max(max_card, B.max_card);
+    ix.n_postings_raw += B.raw;
+    ix.n_postings += B.terms.size();
+  }
+  // global term ids: blocks in docID order, each block's terms in its own first-occurrence order
+  ix.term_of.reserve(1 << 16);
+  for (auto& B : blk) {
+    B.to_global.resize(B.keys.size());
+    for (size_t l = 0; l < B.keys.size(); l++) {
+      auto it = ix.term_of.find(B.keys[l]);
+      if (it == ix.term_of.end()) {
+        B.to_global[l] = (uint32_t)ix.term_key.size();
+        ix.term_of.emplace(B.keys[l], (uint32_t)ix.term_key.size());
+        ix.term_key.push_back(B.keys[l]);
+      } else B.to_global[l] = it->second;
+    }
+    std::unordered_map<uint64_t, uint32_t>().swap(B.local_of);
   }
   // indexer_writer.go:69-73: len(indices) = max cardinality + 1
   const uint32_t S = n_docs ? std::max(max_card + 1, ix.min_segments) : 0;
   ix.n_segments = S;
   const size_t nT = ix.term_key.size();
-  ix.n_postings = doc_terms.size();
+  const size_t nTS = nT * (size_t)S;
+  // the per-block counters below take nTS words per block: past 2 GiB in total, one shared set and a sequential scatter
+  const bool shared = n_thr > 1 && (nTS * n_thr > (1ull << 29) || getenv("SG_BUILD_SHARED_COUNTERS"));
 
-  // pass 2: count per (term, segment), lay the lists out term-major, each padded to 4 postings
-  ix.list_len.assign(nT * (size_t)S, 0);
-  for (uint32_t d = 0; d < n_docs; d++)
-    for (uint64_t p = doc_off[d]; p < doc_off[d + 1]; p++) ix.list_len[(size_t)doc_terms[p] * S + doc_card[d]]++;
+  // pass 2: count per (term, segment) and block, lay the lists out term-major, each padded to 4 postings
+  run_blocks(n_thr, [&](uint32_t b) {
+    BuildBlock& B = blk[b];
+    for (auto& t : B.terms) t = B.to_global[t];
+    for (auto& dp : B.dups) dp.term = B.to_global[dp.term];
+    if (shared) return;
+    B.cursor.assign(nTS, 0);
+    for (uint32_t d = B.d0; d < B.d1; d++)
+      for (uint64_t p = B.off[d - B.d0]; p < B.off[d - B.d0 + 1]; p++) B.cursor[(size_t)B.terms[p] * S + doc_card[d]]++;
+  });
+  ix.list_len.assign(nTS, 0);
+  if (shared) {
+    for (auto& B : blk)
+      for (uint32_t d = B.d0; d < B.d1; d++)
+        for (uint64_t p = B.off[d - B.d0]; p < B.off[d - B.d0 + 1]; p++) ix.list_len[(size_t)B.terms[p] * S + doc_card[d]]++;
+    blk[0].cursor.assign(nTS, 0);
+  } else run_blocks(n_thr, [&](uint32_t b) {     // per (term, segment): total length; each block's count becomes its first slot
+    const size_t i0 = nTS * b / n_thr, i1 = nTS * (b + 1) / n_thr;
+    for (size_t i = i0; i < i1; i++) {
+      uint32_t run = 0;
+      for (auto& B : blk) { const uint32_t c = B.cursor[i]; B.cursor[i] = run; run += c; }
+      ix.list_len[i] = run;
+    }
+  });
   ix.seg_off.assign(nT * (size_t)(S + 1) + 1, 0);
   uint64_t chunk = 0;
   for (size_t t = 0; t < nT; t++) {
@@ -350,25 +429,32 @@ int build_host_index(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs,
     ix.seg_off[t * (S + 1) + S] = (uint32_t)chunk;
     if (chunk >= 0xFFFFFFF0ull) { err = "posting store exceeds 2^32 16-byte chunks"; return SG_E_UNSUPPORTED; }
   }
-  ix.postings.assign((size_t)chunk * 4, 0);
-  std::vector<uint32_t> cursor(nT * (size_t)S, 0);
-  for (uint32_t d = 0; d < n_docs; d++) {           // ascending docID => every list ascending
-    uint32_t b = doc_card[d];
-    for (uint64_t p = doc_off[d]; p < doc_off[d + 1]; p++) {
-      size_t t = doc_terms[p];
-      ix.postings[(size_t)ix.seg_off[t * (S + 1) + b] * 4 + cursor[t * S + b]++] = d;
+  ix.postings.resize((size_t)chunk * 4);
+  auto scatter = [&](BuildBlock& B, std::vector<uint32_t>& cursor) {
+    for (uint32_t d = B.d0; d < B.d1; d++) {
+      const uint32_t s = doc_card[d];
+      for (uint64_t p = B.off[d - B.d0]; p < B.off[d - B.d0 + 1]; p++) {
+        const size_t t = B.terms[p];
+        ix.postings[(size_t)ix.seg_off[t * (S + 1) + s] * 4 + cursor[t * S + s]++] = d;
+      }
     }
-  }
+  };
+  // ascending docID within a block, blocks in docID order => every list ascending
+  if (shared) for (auto& B : blk) scatter(B, blk[0].cursor);
+  else run_blocks(n_thr, [&](uint32_t b) { scatter(blk[b], blk[b].cursor); });
   // pad every list to a whole 16-byte chunk by repeating its last docID: the kernel's lossy counters
   // stay upper bounds and its binary searches stay valid without a per-posting sentinel test
-  for (size_t t = 0; t < nT; t++)
-    for (uint32_t b = 0; b < S; b++) {
-      const uint32_t len = ix.list_len[t * S + b];
-      if (!len || !(len & 3)) continue;
-      uint32_t* p = ix.postings.data() + (size_t)ix.seg_off[t * (S + 1) + b] * 4;
-      for (uint32_t i = len; i < ((len + 3) & ~3u); i++) p[i] = p[len - 1];
-    }
-  for (const auto& rd : raw_dups) ix.dups.push_back(DupEntry{rd.term, doc_card[rd.doc], rd.doc, rd.mult});
+  run_blocks(n_thr, [&](uint32_t b) {
+    for (size_t t = nT * b / n_thr; t < nT * (b + 1) / n_thr; t++)
+      for (uint32_t s = 0; s < S; s++) {
+        const uint32_t len = ix.list_len[t * S + s];
+        if (!len || !(len & 3)) continue;
+        uint32_t* p = ix.postings.data() + (size_t)ix.seg_off[t * (S + 1) + s] * 4;
+        for (uint32_t i = len; i < ((len + 3) & ~3u); i++) p[i] = p[len - 1];
+      }
+  });
+  for (const auto& B : blk)
+    for (const auto& rd : B.dups) ix.dups.push_back(DupEntry{rd.term, doc_card[rd.doc], rd.doc, rd.mult});
   std::sort(ix.dups.begin(), ix.dups.end(), [](const DupEntry& x, const DupEntry& y) {
     if (x.term != y.term) return x.term < y.term;
     if (x.segment != y.segment) return x.segment < y.segment;

@@ -166,7 +166,9 @@ static void TestDevice(const std::string& golden) {
     EXPECT(ok, "SuggestBatch == Suggest");
   }
 
-  {  // service_test.go:36-79: queries run while the index is swapped; a replaced index stays valid until released
+  // service_test.go:36-79: queries run while the index is swapped; a replaced index stays valid until released
+  // (SG_STRESS=n repeats the scenario n times)
+  for (int rep = 0, reps = getenv("SG_STRESS") ? atoi(getenv("SG_STRESS")) : 1; rep < reps; rep++) {
     Service service;
     IndexDescription d = configs[0];
     d.driver = RAMDriver;
@@ -181,6 +183,11 @@ static void TestDevice(const std::string& golden) {
             const Json& exp = t.at("expected_values").at(q);
             bool ok = res.size() == exp.size();
             for (size_t i = 0; ok && i < res.size(); i++) ok = res[i].Value == exp.at(i).str;
+            if (!ok && !bad[w]) {
+              std::string got;
+              for (auto& r : res) got += " [" + r.Value + " " + std::to_string(r.Score) + "]";
+              fprintf(stderr, "worker %d pass %d query '%s': %zu results (want %zu):%s\n", w, it, t.at("queries").at(q).str.c_str(), res.size(), exp.size(), got.c_str());
+            }
             bad[w] += !ok;
           }
       });

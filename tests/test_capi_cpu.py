@@ -91,6 +91,26 @@ def test_words_csr_matches_oracle(words_lines):
     assert all(mine[k] == (ora[k][0], ora[k][1]) for k in ora)
 
 
+def test_threaded_host_build_equals_the_sequential_one(words_lines, cars_lines, monkeypatch):
+    """build_host_index splits the docs into contiguous blocks, one thread each: term numbering (first occurrence over
+    ascending docIDs), list layout and the repeated-term table must not depend on the number of blocks, nor on whether
+    the blocks count into their own or into one shared set of cursors."""
+    from suggest_amd import NGramIndex
+    for lines, desc in ((words_lines, WORDS_DESC), (cars_lines + ["", "aaaaaa", "Škoda škoda"] * 1500, CARS_DESC)):
+        got = {}
+        for thr, shared in (("1", False), ("2", False), ("5", False), ("32", False), ("7", True)):
+            monkeypatch.setenv("SG_BUILD_THREADS", thr)
+            if shared:
+                monkeypatch.setenv("SG_BUILD_SHARED_COUNTERS", "1")
+            else:
+                monkeypatch.delenv("SG_BUILD_SHARED_COUNTERS", raising=False)
+            ix = NGramIndex(lines, _desc(desc), upload=False)
+            got[(thr, shared)] = (ix.digest(), ix.stats())
+            ix.close()
+        first = got[("1", False)]
+        assert all(v == first for v in got.values()), got
+
+
 def test_algorithmic_bytes_matches_oracle_definition():
     from suggest_amd import NGramIndex, IndexDescription, synth
     blob, offs = synth.make_dict(20000, seed=1)

@@ -77,6 +77,49 @@ def test_coalesced_single_query_callers(small):
     assert not errors, errors[:3]
 
 
+def test_host_buffer_callers_during_index_churn(small):
+    """Threads calling the host-buffer batch entry point (each on its own stream) while the main thread builds, uploads
+    and frees other indexes on the same device: every call's rows are its own.  (The detector of the round-2 pool problem
+    is test_cpp_mirror's stress test — under the GIL this one did not reproduce it; it covers the Python entry points.)"""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    gpu, ora, qb, qo = small
+    queries = synth.unpack(qb, qo)[:2048]
+    ids, sc, cnt = gpu.suggest_batch(queries, "jaccard", 0.5, 10)
+    stop = threading.Event()
+    errors, calls = [], [0]
+
+    def worker(t):
+        rng = np.random.default_rng(t)
+        try:
+            while not stop.is_set():
+                n = int(rng.integers(1, 9)); i0 = int(rng.integers(0, len(queries) - n))
+                g_ids, g_sc, g_cnt = gpu.suggest_batch(queries[i0:i0 + n], "jaccard", 0.5, 10)
+                assert np.array_equal(g_cnt, cnt[i0:i0 + n]), (i0, n, g_cnt, cnt[i0:i0 + n])
+                for r in range(n):
+                    m = int(g_cnt[r])
+                    assert np.array_equal(g_ids[r, :m], ids[i0 + r, :m]) and np.array_equal(g_sc[r, :m], sc[i0 + r, :m]), (i0, r)
+                calls[0] += 1
+        except Exception as exc:       # noqa: BLE001
+            errors.append(exc)
+            stop.set()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    blob, offs = synth.make_dict(20000, seed=5)
+    for it in range(40):
+        if stop.is_set():
+            break
+        other = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION), build="host" if it % 2 else "device")
+        other.suggest_batch(queries[:4], "jaccard", 0.5, 10)
+        other.close()
+    stop.set()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert calls[0] > 100
+
+
 def test_single_query_load_generator():
     """tools/single_query_load (C++, through the C ABI): N threads of blocking sg_suggest_one calls; checks every answer
     against the batch call and reports the rate (the number itself is not asserted here: DESIGN.md)"""
