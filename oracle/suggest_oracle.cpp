@@ -311,9 +311,10 @@ using Collect = std::function<bool(Cand)>;  // returns false == ErrCollectionTer
 
 // Go 1.14 sort.Sort (quickSort + ShellSort pass + insertionSort + heapSort), restated
 // from the published algorithm of the Go standard library the reference builds with.
+template <class Less, class Swap>
 struct GoSort {
-  std::function<bool(int, int)> less;
-  std::function<void(int, int)> swap;
+  Less less;     // (functors, inlined: the sort runs once per segment and query on the CPU baseline's hot path)
+  Swap swap;
   void insertion(int a, int b) {
     for (int i = a + 1; i < b; i++)
       for (int j = i; j > a && less(j, j - 1); j--) swap(j, j - 1);
@@ -396,23 +397,21 @@ struct GoSort {
   }
 };
 
+template <class Less, class Swap>
+static void go_sort(int n, Less less, Swap swap) { GoSort<Less, Swap> g{less, swap}; g.sort(n); }
+
 // test hook: the permutation go_sort gives n keys (out[i] = original index of the element that ends at position i)
 extern "C" void or_go_sort(const uint32_t* keys, int n, uint32_t* out) {
   std::vector<uint32_t> k(keys, keys + n);
   for (int i = 0; i < n; i++) out[i] = (uint32_t)i;
-  GoSort g;
-  g.less = [&](int i, int j) { return k[i] < k[j]; };
-  g.swap = [&](int i, int j) { std::swap(k[i], k[j]); std::swap(out[i], out[j]); };
-  g.sort(n);
+  go_sort(n, [&](int i, int j) { return k[i] < k[j]; }, [&](int i, int j) { std::swap(k[i], k[j]); std::swap(out[i], out[j]); });
 }
 
 // sort.Sort(rid) with Rid.Less = Len() < Len() — list_merger.go:23-31
 static void sort_rid(std::vector<Iter>& rid, bool reverse = false) {
-  GoSort g;
-  if (!reverse) g.less = [&](int i, int j) { return rid[i].len < rid[j].len; };
-  else g.less = [&](int i, int j) { return rid[j].len < rid[i].len; };   // sort.Reverse
-  g.swap = [&](int i, int j) { std::swap(rid[i], rid[j]); };
-  g.sort((int)rid.size());
+  auto swap = [&](int i, int j) { std::swap(rid[i], rid[j]); };
+  if (!reverse) go_sort((int)rid.size(), [&](int i, int j) { return rid[i].len < rid[j].len; }, swap);
+  else go_sort((int)rid.size(), [&](int i, int j) { return rid[j].len < rid[i].len; }, swap);   // sort.Reverse
 }
 
 // One list folded into the running candidate array: the loop shared by
@@ -626,12 +625,22 @@ struct TopK {
 // what resolvePostingList codec.go:76-89 dispatches on).
 // ---------------------------------------------------------------------------------
 struct StoredList { std::vector<uint32_t> v; int raw_len = 0; };
-struct Segment { std::unordered_map<std::string, StoredList> terms; };
+struct Segment {
+  std::unordered_map<std::string, StoredList> terms;
+  std::vector<const StoredList*> by_id;         // commit(): the same lists by dense term id (nullptr: not in this segment)
+};
 
 struct Index {
   Description d;
   std::vector<std::unique_ptr<Segment>> segs;   // nullptr == empty segment (indices.go:27-33)
+  std::unordered_map<std::string, int> term_id; // commit(): every term of the index -> dense id; a query resolves its
+                                                // terms once instead of hashing the strings again in every segment
 };
+static std::vector<int> term_ids(const Index& ix, const std::vector<std::string>& terms) {
+  std::vector<int> ids(terms.size(), -1);
+  for (size_t i = 0; i < terms.size(); i++) { auto it = ix.term_id.find(terms[i]); if (it != ix.term_id.end()) ids[i] = it->second; }
+  return ids;
+}
 
 static void add_document(Index& ix, uint32_t id, const std::vector<std::string>& terms) {
   size_t card = terms.size();
@@ -651,18 +660,25 @@ static void commit(Index& ix) {
       l.v.shrink_to_fit();
     }
   }
+  ix.term_id.clear();
+  for (auto& s : ix.segs) if (s) for (auto& kv : s->terms) ix.term_id.emplace(kv.first, (int)ix.term_id.size());
+  for (auto& s : ix.segs) {
+    if (!s) continue;
+    s->by_id.assign(ix.term_id.size(), nullptr);
+    for (auto& kv : s->terms) s->by_id[ix.term_id.at(kv.first)] = &kv.second;    // (node addresses are stable)
+  }
 }
 
 static inline int stored_len(const StoredList& l) { return l.raw_len > 256 ? (int)l.v.size() : l.raw_len; }
 
 // searcher.Search + filterTermsByExistence — searcher.go:28-78
-static void search(const Segment& seg, const std::vector<std::string>& terms, int threshold, int algo,
+static void search(const Segment& seg, const std::vector<int>& terms, int threshold, int algo,
                    const Collect& collect) {
   int n = (int)terms.size();
   std::vector<const StoredList*> kept;
   for (int i = 0; i < n && ((int)kept.size() + n - i) >= threshold; i++) {
-    auto it = seg.terms.find(terms[i]);
-    if (it != seg.terms.end()) kept.push_back(&it->second);
+    const StoredList* l = terms[i] >= 0 ? seg.by_id[terms[i]] : nullptr;
+    if (l) kept.push_back(l);
   }
   if ((int)kept.size() < threshold) return;
   std::vector<Iter> rid;
@@ -692,12 +708,13 @@ static std::vector<Candidate> suggest(const Index& ix, const std::string& query,
   if (b_max - b_min + 1 == 0) { if (status) *status = 2; return {}; }
   TopK global(k);
   double sim = similarity;
+  const std::vector<int> token_ids = term_ids(ix, tokens);
   auto visit = [&](int size_b) {
     int threshold = metric_threshold(metric, sim, size_a, size_b);
     if (threshold == 0 || threshold > size_b || threshold > size_a) return;
     if (size_b < 0 || size_b >= len_indices || !ix.segs[size_b]) return;
     TopK local(k);
-    search(*ix.segs[size_b], tokens, threshold, algo, [&](Cand c) {
+    search(*ix.segs[size_b], token_ids, threshold, algo, [&](Cand c) {
       local.add(c.pos, 1 - metric_distance(metric, (int)c.overlap, size_a, size_b));  // scorer.go:29-31
       return true;
     });
@@ -717,10 +734,11 @@ static std::vector<Candidate> autocomplete(const Index& ix, const std::string& q
   auto terms = tokenize(ix.d, query, true);
   int terms_len = (int)terms.size();
   TopK queue(limit);
+  const std::vector<int> ids = term_ids(ix, terms);
   for (int size = terms_len; size < (int)ix.segs.size(); size++) {
     if (!ix.segs[size]) continue;
     std::vector<uint32_t> items;
-    search(*ix.segs[size], terms, terms_len, algo, [&](Cand c) {
+    search(*ix.segs[size], ids, terms_len, algo, [&](Cand c) {
       if ((int)items.size() == limit) return false;
       items.push_back(c.pos);
       return true;
