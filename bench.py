@@ -16,7 +16,8 @@ optional gather of the k*(u32,f64) result rows over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline      achieved = ALGORITHMIC bytes per launch (sg_suggest_algorithmic_bytes) / the search
                 kernel's average launch duration (HIP events on the launch stream); traffic = HBM bytes per launch
-                from the committed rocprofv3 PMC run of this exact workload (profiles/traffic.json), with
+                from a rocprofv3 --pmc FETCH_SIZE pass over this workload — live in a child process (--traffic), else the
+                committed run in profiles/traffic.json — with
                 wire_gbps / wire_frac = that traffic over the same duration
   cpu_baseline  the CPU oracle — a C++ restatement of the Go path, kind "port" — on this host: all hardware
                 threads, and one thread (`one_thread`), each on a bounded sample of the same batch
@@ -68,7 +69,11 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc run, reported as roofline.traffic (default: the figure "
                          "recorded in profiles/traffic.json for this exact workload, measured with tools/pmc_run.sh)")
-    ap.add_argument("--require-traffic", action="store_true", help="exit non-zero when profiles/traffic.json has no entry for the workload")
+    ap.add_argument("--require-traffic", action="store_true", help="exit non-zero when no traffic figure could be had for the workload")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
+                    help="roofline.traffic: live = a rocprofv3 --pmc FETCH_SIZE pass over this same workload in a child process "
+                         "(after the timed region; N=1 only); file = the committed measurement in profiles/traffic.json; "
+                         "auto = live when rocprofv3 is there, else file")
     args = ap.parse_args()
     if args.config == "cfg5":
         import bench_spell
@@ -237,7 +242,12 @@ def main():
 
     key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (args.dict_size, n_q, args.ngram, args.metric, args.similarity, k, args.dict_variant)
     traffic, traffic_src = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes else None)
-    if traffic is None:      # PMC counters cannot be read inside this process: use the committed measurement of this workload
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)     # (no profiler inside a profiler)
+    if traffic is None and args.traffic in ("auto", "live") and rank == 0 and world == 1 and not (under_profiler and args.traffic == "auto"):
+        traffic, traffic_src = _live_traffic(args, log)
+        if traffic is None and args.traffic == "live":
+            raise SystemExit("live PMC pass failed: " + str(traffic_src))
+    if traffic is None and args.traffic != "none":      # the committed measurement of this workload
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
             if rec:
@@ -303,6 +313,52 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _live_traffic(args, log):
+    """HBM bytes per launch of the search kernel, measured now: this script again, as a child under `rocprofv3 --pmc
+    FETCH_SIZE --kernel-trace` (PMC counters cannot be read from inside a process), a few steps of the same workload.
+    bytes = FETCH_SIZE [KB] x 1024 x 2 — the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).
+    -> (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
+    steps, warm = 4, 2
+    cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+           os.path.abspath(__file__), "--config", args.config, "--dict-size", str(args.dict_size), "--queries", str(args.queries),
+           "--ngram", str(args.ngram), "--metric", args.metric, "--similarity", repr(args.similarity), "--topk", str(args.topk),
+           "--batches", str(args.batches), "--dict-variant", args.dict_variant, "--build", args.build,
+           "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none"]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+        if r.returncode != 0:
+            return None, "rocprofv3 child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:])
+        main_k, parts_k = [], []
+        for path in sorted(glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)):
+            for row in csv.DictReader(open(path)):
+                if row.get("Counter_Name") != "FETCH_SIZE":
+                    continue
+                if "sg_search_kernel_t<false, false>" in row["Kernel_Name"]:
+                    main_k.append(float(row["Counter_Value"]))
+                elif "sg_search_kernel_t<true, false>" in row["Kernel_Name"]:
+                    parts_k.append(float(row["Counter_Value"]))
+        if not main_k:
+            return None, "no FETCH_SIZE rows for the search kernel in the child's counter CSV"
+        kb = sum(main_k) / len(main_k) + (sum(parts_k) / len(main_k) if parts_k else 0.0)
+        log("live PMC pass: FETCH_SIZE %.6g KB per launch over %d launches (%.0fs)" % (kb, len(main_k), time.time() - t0))
+        return kb * 1024 * 2, ("live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass of this run, %d launches of this workload "
+                               "(search + parts kernels): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (len(main_k), kb))
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
+        return None, "live PMC pass failed: %r" % (exc,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _human(n):

@@ -15,7 +15,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "GRBM_GUI_ACTIVE TA_BUSY_avr" \
            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pass$i -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pass$i -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --traffic none "$@" > $OUT/pass$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

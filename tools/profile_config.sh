@@ -17,10 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --config $CFG "$@" > $O/${TAG}_bench_$CFG.json 2> $O/${TAG}_bench_$CFG.err
 W=3; K=6
 rm -rf $O/${TAG}_trace_$CFG
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_$CFG -- python $R/bench.py --config $CFG --steps $K --warmup $W --no-cpu-baseline "$@" > $O/${TAG}_trace_$CFG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_$CFG -- python $R/bench.py --config $CFG --steps $K --warmup $W --no-cpu-baseline --traffic none "$@" > $O/${TAG}_trace_$CFG.log 2>&1
 python $R/tools/kernel_stats.py $O/${TAG}_trace_$CFG --skip $W > $O/${TAG}_kernel_stats_$CFG.csv
 rm -rf $O/${TAG}_fetch_$CFG
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch_$CFG -- python $R/bench.py --config $CFG --steps $K --warmup $W --no-cpu-baseline "$@" > $O/${TAG}_fetch_$CFG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch_$CFG -- python $R/bench.py --config $CFG --steps $K --warmup $W --no-cpu-baseline --traffic none "$@" > $O/${TAG}_fetch_$CFG.log 2>&1
 python - "$O/${TAG}_fetch_$CFG" "$O/${TAG}_bench_$CFG.json" "$TAG" "$CFG" > $O/${TAG}_traffic_$CFG.json <<'PY'
 import csv, glob, json, sys
 d, bench, tag, cfg = sys.argv[1:5]
