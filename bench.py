@@ -345,9 +345,9 @@ def _live_traffic(args, log):
             for row in csv.DictReader(open(path)):
                 if row.get("Counter_Name") != "FETCH_SIZE":
                     continue
-                if "sg_search_kernel_t<false, false>" in row["Kernel_Name"]:
+                if "sg_search_kernel_t<false, false," in row["Kernel_Name"]:
                     main_k.append(float(row["Counter_Value"]))
-                elif "sg_search_kernel_t<true, false>" in row["Kernel_Name"]:
+                elif "sg_search_kernel_t<true, false," in row["Kernel_Name"]:
                     parts_k.append(float(row["Counter_Value"]))
         if not main_k:
             return None, "no FETCH_SIZE rows for the search kernel in the child's counter CSV"

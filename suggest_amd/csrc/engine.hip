@@ -113,6 +113,7 @@ struct BatchArgs {
   // a launch over a subset of the batch (the spellchecker's fuzzy top-up): workgroup b runs query q_sel[b], b < *q_sel_n
   const uint32_t* q_sel;
   const uint32_t* q_sel_n;
+  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries}: cumulative, one query in 32
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -167,6 +168,13 @@ __device__ double d_score(int m, int inter, int a, int b) {  // 1 - Distance(...
   return 1 - dist;
 }
 // order-preserving map double -> u64 (bigger = better score)
+__device__ __forceinline__ uint64_t score_bits(double x);
+// Threshold tightening (suggester.go:67-68,101-103, restated exactly): once the top-k is full, a document of segment b can
+// only enter it with a score >= the k-th best, i.e. with an overlap >= the smallest o whose score reaches it.  Scores are
+// compared as the bit patterns the results carry, upwards from the metric's own threshold — no inverse formula, no
+// rounding argument; ties stay in (the docID decides them at the insertion).  Returns omax + 1 when no overlap will do.
+__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s);
+
 __device__ __forceinline__ uint64_t score_bits(double x) {
   uint64_t b = (uint64_t)__double_as_longlong(x);
   return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
@@ -174,6 +182,10 @@ __device__ __forceinline__ uint64_t score_bits(double x) {
 __device__ __forceinline__ double bits_score(uint64_t k) {
   uint64_t b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
   return __longlong_as_double((long long)b);
+}
+__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s) {
+  while (t <= omax && score_bits(d_score(m, t, a, b)) < worst_s) t++;
+  return t;
 }
 __device__ __forceinline__ bool better(uint64_t s1, uint32_t i1, uint64_t s2, uint32_t i2) {
   return s1 > s2 || (s1 == s2 && i1 < i2);  // Candidate.Less inverted, collector.go:20-26
@@ -746,7 +758,10 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 // kLM = true: the spellchecker's autocomplete (candidates ranked by the language model) — its own instantiation, so the
 // search kernel proper carries none of its registers (with the LM code inlined the shared kernel spilled 750 bytes per
 // lane and the headline batch went from 2.6 to 4.4 ms).
-template <bool kParts, bool kLM>
+// kTight = true: threshold tightening (see d_tighten) — pays where queries have many more matches than k (real
+// dictionaries: cars +19 %, words +38 %) and costs the others ~4 % in registers, so it is its own instantiation too; the
+// host picks per launch from the share of recent queries whose top-k filled (fill_stat).
+template <bool kParts, bool kLM, bool kTight>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
@@ -773,7 +788,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   static_assert(SG_DUP_SCRATCH <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64 + SG_QH + SG_QH / 4,
                 "dup scratch must fit row table + dummies + hash");   // (the epoch ring behind the hash is NOT part of it)
   uint32_t* ep_ring = qh_key + SG_QH + SG_QH / 4;   // [SG_EPOCHS][6] streamed-list mask (128 bits over query positions) + docID range of a group pass
-  uint32_t* tk_id_lds = ep_ring + SG_EPOCH_WORDS * SG_EPOCHS;    // top-k rows: min(k, SG_K_LDS) ids, then as many 64-bit scores
+  // {k-th best score the tile's thresholds were tightened against (2 words), first segment still to come, -}: in LDS, not
+  // in scalar registers — the stream loop has none to spare
+  uint32_t* tile_state = ep_ring + SG_EPOCH_WORDS * SG_EPOCHS;
+  uint32_t* tk_id_lds = tile_state + 4;                          // top-k rows: min(k, SG_K_LDS) ids, then as many 64-bit scores
   uint64_t* tk_s_lds = (uint64_t*)(tk_id_lds + ((min(a.k, (uint32_t)SG_K_LDS) + 1u) & ~1u));
   // tokeniser scratch inside the counter region: runes[SG_MAX_RUNES] then keys[SG_MAX_A]
   uint32_t* runes = cnt;
@@ -869,7 +887,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       rows[e] = t == kNoTerm ? 0u : ix.seg_off[(uint64_t)t * (uint32_t)(S + 1) + (uint32_t)tb + w];
     }
     __syncthreads();
-    // ---- lane w owns segment tb+w: posting volume, present terms, threshold ----
+    // ---- lane w owns segment tb+w: posting volume, present terms, threshold.  kTight: computed again (for the segments
+    //      still to come, w >= w_start) whenever the k-th best score has moved: the thresholds tighten with it. ----
+    if (kTight && lane == 0) tile_state[2] = 0u;
+    for (;;) {
+    int w_start = 0;
+    if (kTight) { __syncthreads(); w_start = (int)tile_state[2]; }
     uint32_t seg_tot = 0;
     int seg_T = 0;
     bool seg_valid = false;
@@ -884,15 +907,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       else {
         seg_T = d_threshold(a.metric, a.alpha, A, B);
         seg_valid = !(seg_T == 0 || seg_T > B || seg_T > A);       // suggester.go:76
+        if (kTight && seg_valid && tk.n == k) {                      // the top-k is full
+          // (a query that repeats a term counts it per occurrence: overlaps reach A even where B is smaller)
+          seg_T = d_tighten(a.metric, seg_T, A, A, B, tk.worst_s);
+          seg_valid = seg_T <= A;
+        }
       }
-      seg_valid = seg_valid && (int)ne >= seg_T;                     // searcher.go:32 (fewer present terms than T)
+      seg_valid = seg_valid && (int)ne >= seg_T && (!kTight || lane >= w_start);   // searcher.go:32 (fewer present terms than T)
     }
     const uint64_t vmask = ballot(seg_valid);
+    if (kTight && lane == 0) {                                       // the k-th best score these thresholds were tightened against
+      const uint64_t ts = tk.n == k ? tk.worst_s : 0ull;
+      tile_state[0] = (uint32_t)ts; tile_state[1] = (uint32_t)(ts >> 32);
+    }
+    bool again = false;
     // ---- split decision (first launch, top-k in LDS): a tile whose admissible lists hold >= 2 x split_chunks chunks
     //      is cut into parts of consecutive segments of about equal volume, which are queued for the second launch;
     //      this wavefront goes on with the next tile.  A lone heavy query would otherwise be one wavefront's serial
     //      work (skewed dictionaries: 40x the mean) and set the batch's latency. ----
-    if (splitting && primary && k <= SG_K_LDS && qi < a.slot_cap) {
+    if (splitting && primary && k <= SG_K_LDS && qi < a.slot_cap && (!kTight || w_start == 0)) {
       const uint32_t vol = seg_valid ? seg_tot : 0u;
       const uint32_t incl = wave_scan_incl(vol, lane);
       const uint32_t total = readlane(incl, 63);
@@ -929,7 +962,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             dense++;
           }
           pushed += n_parts;
-          continue;                                          // this tile's parts run in the second launch
+          break;                                             // this tile's parts run in the second launch (on to the next tile)
         }
       }
     }
@@ -981,7 +1014,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           uint64_t fm[2];
           __syncthreads();
           exact_masks(d, w, fm);
-          const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T, d, fm[0], fm[1], lane);
+          // (which secondary entries CPMerge produces depends on the threshold it ran with: the metric's own, not the tightened one)
+          const int T0 = a.autocomplete ? A : d_threshold(a.metric, a.alpha, A, tb + w);
+          const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T0, d, fm[0], fm[1], lane);
           const uint32_t* extra = dup_scratch + 2 * SG_MAX_A + 64;
           for (int x = 0; x < n_extra; x++) offer(d, (int)extra[x], w);
           __syncthreads();
@@ -1122,8 +1157,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       seg_need = max(1u, buckets_needed(rem * 4u, seg_T - k, a.filter_level));
     }
 
+    // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
+    const bool tightening = kTight && !kLM && !a.autocomplete;
+    auto tightened_against = [&]() -> uint64_t { return (uint64_t)tile_state[0] | ((uint64_t)tile_state[1] << 32); };
     int wnext = DBG_SKIP(16u) ? Wt : 0;
     while (wnext < Wt) {
+      if (tightening && tk.n == k && tk.worst_s != tightened_against()) {   // the k-th best score moved: the segments still
+        if (lane == 0) tile_state[2] = (uint32_t)wnext;                      // to come get their thresholds again (the queue
+        again = true;                                                        // is empty here: see the end of the pass loop)
+        break;
+      }
       const uint64_t rest = (vmask >> wnext) << wnext;
       if (!rest) break;
       const int g0 = __builtin_ctzll(rest);
@@ -1254,7 +1297,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
       uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
       uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
-      const bool last_group = wnext >= Wt || (vmask >> wnext) == 0ull;
       for (uint32_t pass = 0; pass < n_pass; pass++) {
       DBG_COUNT(4, 1)
       if (n_pass > 1) {
@@ -1472,10 +1514,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       // candidates wait across passes and groups (one verification of many instead of many of few); they are verified
       // when the next pass would reuse a live ring slot, when the queue is half full, and before the tile's segment table goes
+      // A group after which the thresholds are due to be tightened (the k-th best score moved since the last time) ends
+      // with an empty queue: the tightening at the top of the next group may leave nothing more to stream.
+      const bool last_group = wnext >= Wt || (vmask >> wnext) == 0ull || (tightening && tk.n == k && tk.worst_s != tightened_against());
       if (epoch + 1u - flushed_at >= SG_EPOCHS || qn > cq_cap / 2 || (last_group && pass + 1u == n_pass)) flush_queue();
       }  // docID-range passes
       lo_doc = 0; hi_doc = 0xFFFFFFFFu;
     }
+    if (!kTight || !again) break;
+    }  // segment statistics, again after a tightening
   }
 
   // ---- a part of a split query hands its top-k over; the part that finishes last merges them all (top-k of a
@@ -1533,6 +1580,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
+  if (!kLM && !a.autocomplete && a.fill_stat && lane == 0 && (qi & 31u) == 0u) {
+    atomicAdd(a.fill_stat + 1, 1u);
+    if (n == k) atomicAdd(a.fill_stat, 1u);
+  }
   if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 2] = (uint32_t)(qe - qb); out_ids[k - 3] = qi; out_ids[k - 4] = (uint32_t)qb; }
   PH(7)
   } while (0);
@@ -1670,9 +1721,11 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
   for (uint32_t i = threadIdx.x; i < n; i += 64) out_vals[i] = v[i];
 }
 
-#define sg_search_kernel sg_search_kernel_t<false, false>
-#define sg_parts_kernel sg_search_kernel_t<true, false>
-#define sg_lm_kernel sg_search_kernel_t<false, true>
+#define sg_search_kernel sg_search_kernel_t<false, false, false>
+#define sg_search_kernel_tight sg_search_kernel_t<false, false, true>
+#define sg_parts_kernel sg_search_kernel_t<true, false, false>
+#define sg_parts_kernel_tight sg_search_kernel_t<true, false, true>
+#define sg_lm_kernel sg_search_kernel_t<false, true, false>
 
 }  // namespace sg
 

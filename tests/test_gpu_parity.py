@@ -114,11 +114,13 @@ def test_service_cars_golden(reference_tests, cars_lines):
         assert [r.value for r in res] == exp, q
 
 
-def test_cars_all_lines_as_queries(cars_lines):
+@pytest.mark.parametrize("tighten", [0, 1, 2])
+def test_cars_all_lines_as_queries(cars_lines, tighten):
     """Every third dictionary line (and edited copies) as a query, several metrics, ALL rows compared — including
-    the rows where the reference returns a document twice (documents that repeat a term)."""
+    the rows where the reference returns a document twice (documents that repeat a term).  With and
+    without threshold tightening (its own kernel instantiation; 2 = picked per launch from what recent queries did)."""
     from suggest_amd import NGramIndex
-    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC)).tune(SG_TIGHTEN=tighten)
     ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
     queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]] + [l.lower()[:-2] for l in cars_lines[::11]]
     qb, qo = oracle.pack_strings(queries)
@@ -152,9 +154,11 @@ def test_words_parity(words_lines, reference_tests):
     queries = reference_tests["workloads"]["words_cosine_0.5_k5"] + [w for w in words_lines[::997]] + \
         [w[:-1] + b"q" for w in words_lines[5::1999]]
     qb, qo = oracle.pack_strings(queries)
-    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.4, 10)]:
-        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k),
-                    ora.suggest_batch(qb, qo, metric, alpha, k), queries)
+    for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.4, 10), ("dice", 0.45, 1), ("cosine", 0.3, 3)]:
+        want = ora.suggest_batch(qb, qo, metric, alpha, k)
+        for tighten in (0, 1):        # both kernel instantiations (threshold tightening off / on)
+            gpu.tune(SG_TIGHTEN=tighten)
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), want, queries)
 
 
 def test_autocomplete_parity(words_lines, cars_lines):
@@ -287,9 +291,9 @@ def test_saturating_bucket_and_candidate_overflow():
     assert np.array_equal(ids[valid], oi[valid])
 
 
-@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9", SG_SPLIT_CHUNKS="0"),
-                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12", SG_SPLIT_CHUNKS="8"),
-                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10", SG_SPLIT_CHUNKS="200")])
+@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9", SG_SPLIT_CHUNKS="0", SG_TIGHTEN="1"),
+                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12", SG_SPLIT_CHUNKS="8", SG_TIGHTEN="0"),
+                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10", SG_SPLIT_CHUNKS="200", SG_TIGHTEN="1")])
 def test_results_do_not_depend_on_tuning_knobs(monkeypatch, knobs):
     """The lossy counters are only a filter (every flagged doc is verified exactly), so list-skipping depth,
     bucket-table strictness and counter-array size must not change a single output bit (DESIGN.md §4 knobs)."""

@@ -25,7 +25,7 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
         name = b.split()[0]
         m = {k: int(v) for k, v in re.findall(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", b)}
         found[name] = m
-    batch = [v for k, v in found.items() if "sg_search_kernel_tILb0ELb0" in k]
+    batch = [v for k, v in found.items() if "sg_search_kernel_tILb0ELb0ELb0E" in k]
     assert len(batch) == 1, list(found)
     assert batch[0]["ScratchSize [bytes/lane]"] <= 64, batch[0]      # a few spilled dwords in cold code are fine (hot blocks checked below)
     assert batch[0]["Occupancy [waves/SIMD]"] >= 3, batch[0]
@@ -34,7 +34,7 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
     # the stream loop keeps the next batch's four row loads in flight while it counts the current batch: the blocks
     # that issue the LDS counter atomics wait with vmcnt(4), never with vmcnt(0), and touch no scratch
     asm = open(tmp_path / "engine.s").read().split("\n")
-    start = next(i for i, l in enumerate(asm) if l.startswith("_ZN2sg18sg_search_kernel_tILb0ELb0"))
+    start = next(i for i, l in enumerate(asm) if l.startswith("_ZN2sg18sg_search_kernel_tILb0ELb0ELb0E"))
     end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
     blocks, cur = [], []
     for l in asm[start:end]:

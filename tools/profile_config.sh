@@ -27,12 +27,12 @@ d, bench, tag, cfg = sys.argv[1:5]
 vals = []
 for p in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(p)):
-        if "sg_search_kernel_t<false, false>" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+        if "sg_search_kernel_t<false, false," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             vals.append(float(r["Counter_Value"]))
 parts = []
 for p in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(p)):
-        if "sg_search_kernel_t<true, false>" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+        if "sg_search_kernel_t<true, false," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             parts.append(float(r["Counter_Value"]))
 out = {"config": cfg, "tag": tag, "dispatches": len(vals)}
 if vals:
