@@ -333,8 +333,19 @@ int lm_build_google_files(const uint8_t* text, size_t n, uint32_t order, const c
 
 void lm_tokenize(const HostLM& lm, const uint8_t* text, size_t n, std::vector<std::string>& out) {
   // strings.ToLower, strings.Trim(" "), then maximal runs of alphabet runes
-  std::vector<uint32_t> runes;
+  // (ASCII membership from a table made on first use: the alphabet of a model does not change once it is loaded)
+  struct AsciiAlpha { uint64_t key = 0; uint8_t has[128]; };
+  static thread_local AsciiAlpha aa;
+  uint64_t key = 0xCBF29CE484222325ull ^ lm.alphabet.size();      // FNV-1a over the alphabet specification
+  for (const auto& part : lm.alphabet) { for (unsigned char c : part) key = (key ^ c) * 0x100000001B3ull; key = (key ^ 0xFF) * 0x100000001B3ull; }
+  if (aa.key != key) {
+    for (uint32_t r = 0; r < 128; r++) aa.has[r] = host_alphabet_has(lm.alphabet, r) ? 1 : 0;
+    aa.key = key;
+  }
+  static thread_local std::vector<uint32_t> runes;
+  runes.clear();
   for (size_t i = 0; i < n;) {
+    if (text[i] < 0x80) { const uint32_t c = text[i++]; runes.push_back(c >= 'A' && c <= 'Z' ? c + 32 : c); continue; }
     size_t adv;
     runes.push_back(host_lower_rune(host_next_rune(text + i, n - i, &adv)));
     i += adv;
@@ -347,7 +358,7 @@ void lm_tokenize(const HostLM& lm, const uint8_t* text, size_t n, std::vector<st
   auto flush = [&] { if (!cur.empty()) { out.push_back(cur); cur.clear(); } };
   for (size_t i = a; i < b; i++) {
     const uint32_t r = runes[i];
-    if (!host_alphabet_has(lm.alphabet, r)) { flush(); continue; }
+    if (!(r < 128 ? aa.has[r] != 0 : host_alphabet_has(lm.alphabet, r))) { flush(); continue; }
     if (r < 0x80) cur.push_back((char)r);
     else if (r < 0x800) { cur.push_back((char)(0xC0 | (r >> 6))); cur.push_back((char)(0x80 | (r & 0x3F))); }
     else if (r < 0x10000) { cur.push_back((char)(0xE0 | (r >> 12))); cur.push_back((char)(0x80 | ((r >> 6) & 0x3F))); cur.push_back((char)(0x80 | (r & 0x3F))); }
