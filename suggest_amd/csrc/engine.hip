@@ -33,19 +33,44 @@ namespace sg {
 
 #define SG_MAX_A 128           // == SG_MAX_QUERY_TERMS
 #define SG_MAX_RUNES 144       // SG_MAX_A + 2*8 wrap runes
-#define SG_CAND_CAP 64
 #define SG_K_LDS 64
 #define SG_WRAP_MAX 8
-#define SG_ROWS_CAP 512    // u32 entries of seg_off rows kept in LDS per tile
 #define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path (borrowed from the row table)
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
-#define SG_ROWTAB_CAP 84      // row descriptors (8 B + 1 B) per streaming window
-#define SG_QH 192             // slots of the query-term hash (LDS): A <= 128 occurrences, load <= 0.67
-#define SG_CAND_BIG 112       // the candidate queue of launches whose top-k rows leave the room (k <= SG_K_BIGQ)
 #define SG_EPOCHS 4           // group passes whose candidates may wait in the queue together (ring of their streamed-list masks + docID ranges)
 #define SG_EPOCH_WORDS 6
-#define SG_K_BIGQ 21
+// LDS layout of a search wavefront.  Two sets of table sizes: the full one, and a slim one that — with 2^11 counter words,
+// k <= 20 and the small candidate queue — fits 12 800 B = 10 allocation granules, i.e. a 12th wavefront per CU (headline
+// +4.5 %, cfg 2 +6 %, cfg 3 +5 %).  Where the slim tables buy no wavefront (2^12 counters: long-list indexes; the large
+// queue of launches with many results) they only cost (skewed 10M -11 %, families -3.5 %), so the host picks per launch.
+template <bool kSlim> struct Lds {
+  static constexpr uint32_t rows_cap = kSlim ? 448u : 512u;     // u32 entries of seg_off rows kept in LDS per tile
+  static constexpr uint32_t rowtab_cap = kSlim ? 64u : 84u;     // row descriptors (8 B + 1 B) per streaming window
+  static constexpr uint32_t qh = kSlim ? 144u : 192u;           // slots of the query-term hash: A <= 128 occurrences (typical A ~ 20)
+  static constexpr uint32_t dedup = kSlim ? 96u : 128u;         // slots of the in-batch (doc, list) table of flush_queue
+  static constexpr uint32_t rowtab_words = 2u * (rowtab_cap + 2u * SG_UNROLL) + (rowtab_cap + 2u * SG_UNROLL + 7u) / 8u * 2u;   // descriptors + list ids
+  // everything besides the counters, the candidate queue and the top-k rows
+  static constexpr uint32_t fixed_words = SG_MAX_A + rows_cap + rowtab_words + 64u + qh + qh / 4u + SG_EPOCH_WORDS * SG_EPOCHS + 4u;
+  static_assert(qh > SG_MAX_A && qh % 4u == 0u && qh <= 256u, "the query-term hash needs a free slot and whole words of positions");
+  static_assert(SG_DUP_SCRATCH <= rowtab_words + 64u + qh + qh / 4u, "dup scratch must fit row table + dummies + hash");
+  static_assert(2u * dedup <= rowtab_words + 64u, "dedup table must fit row table + dummies");
+};
+// The queue gets what is left of the wavefront's share of the CU's LDS: 160 KB in allocation granules of 1 280 B (320
+// words), so a wavefront that needs g granules with the smallest useful queue (40 entries; 112 for the launches that
+// expect many candidates) runs 128 / g to a CU and may as well use all of 128 / (128 / g) granules.
+inline uint32_t sg_topk_words(uint32_t k) { const uint32_t kk = k < SG_K_LDS ? k : SG_K_LDS; return ((kk + 1u) & ~1u) + 2u * kk; }
+inline uint32_t sg_lds_waves(uint32_t log2_cnt, uint32_t k, bool roomy, bool slim) {
+  const uint32_t used = (1u << log2_cnt) + (slim ? Lds<true>::fixed_words : Lds<false>::fixed_words) + sg_topk_words(k);
+  return 128u / ((used + 2u * (roomy ? 112u : 40u) + 319u) / 320u);
+}
+inline uint32_t sg_queue_cap(uint32_t log2_cnt, uint32_t k, bool roomy, bool slim) {
+  const uint32_t used = (1u << log2_cnt) + (slim ? Lds<true>::fixed_words : Lds<false>::fixed_words) + sg_topk_words(k);
+  const uint32_t waves = sg_lds_waves(log2_cnt, k, roomy, slim);
+  if (waves == 0u) return 64u;
+  const uint32_t c = (((128u / waves) * 320u - used) / 2u) & ~7u;
+  return c < 112u ? c : 112u;
+}
 #define SG_MAX_PARTS 32       // parts a heavy query is cut into
 
 struct DeviceIndex {
@@ -96,6 +121,7 @@ struct BatchArgs {
   uint32_t log2_cnt;    // LDS counter words per wave = 1 << log2_cnt
   int t_floor;          // lowest flag threshold list skipping may leave
   uint32_t filter_level;  // row of kBucketsPer16Postings: how rarely a bucket may reach T by chance
+  uint32_t cq_cap;        // entries of the candidate queue (sg_queue_cap: what the LDS budget leaves)
   // ---- heavy queries are cut into parts (ranges of segments) that other wavefronts take over ----
   uint32_t* split_ctl;    // [2] items taken (second launch), items queued (first launch); null: splitting off.  Zeroed per batch.
   uint32_t* items;        // [item_cap][4] {query, seg_lo | seg_hi << 16, slot | part << 24, -}
@@ -113,7 +139,7 @@ struct BatchArgs {
   // a launch over a subset of the batch (the spellchecker's fuzzy top-up): workgroup b runs query q_sel[b], b < *q_sel_n
   const uint32_t* q_sel;
   const uint32_t* q_sel_n;
-  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries}: cumulative, one query in 32
+  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative, one query in 32
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -276,9 +302,8 @@ __device__ uint64_t d_mix64(uint64_t k) {
   k ^= k >> 31;
   return k;
 }
-__device__ __forceinline__ uint32_t d_qhash(uint32_t term) { return (((term * 0x9E3779B1u) >> 24) * 3u) >> 2; }   // slot of SG_QH = 192
-__device__ __forceinline__ uint32_t d_qnext(uint32_t h) { return h + 1u == SG_QH ? 0u : h + 1u; }
-static_assert(SG_QH == 192, "d_qhash maps 8 bits onto 3/4 of 256");
+template <uint32_t kQH> __device__ __forceinline__ uint32_t d_qhash(uint32_t term) { return (((term * 0x9E3779B1u) >> 24) * kQH) >> 8; }   // 8 hash bits onto kQH slots
+template <uint32_t kQH> __device__ __forceinline__ uint32_t d_qnext(uint32_t h) { return h + 1u == kQH ? 0u : h + 1u; }
 __device__ uint32_t d_term_lookup(const DeviceIndex& ix, uint64_t key) {
   uint32_t h = (uint32_t)d_mix64(key) & ix.slot_mask;
   for (;;) {
@@ -761,8 +786,9 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], cons
 // kTight = true: threshold tightening (see d_tighten) — pays where queries have many more matches than k (real
 // dictionaries: cars +19 %, words +38 %) and costs the others ~4 % in registers, so it is its own instantiation too; the
 // host picks per launch from the share of recent queries whose top-k filled (fill_stat).
-template <bool kParts, bool kLM, bool kTight>
+template <bool kParts, bool kLM, bool kTight, bool kSlim>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
+  using L = Lds<kSlim>;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
   const DeviceIndex& ix = a.ix;
@@ -771,23 +797,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32*)cnt;   // LDS byte address of the counters (aligned to their size)
   uint32_t* term = cnt + cnt_words;
   uint32_t* rows = term + SG_MAX_A;
-  const uint32_t cq_cap = a.k <= SG_K_BIGQ ? SG_CAND_BIG : SG_CAND_CAP;   // (the LDS a small k leaves goes to the queue)
-  uint32_t* cq_doc = rows + SG_ROWS_CAP;            // candidate queue: docs whose bucket reached the flag threshold ...
+  const uint32_t cq_cap = a.cq_cap;                                  // (what the LDS budget leaves: sg_queue_cap, set by the host —
+                                                                     //  computed here, the LDS pointers behind the queue cost registers)
+  uint32_t* cq_doc = rows + L::rows_cap;            // candidate queue: docs whose bucket reached the flag threshold ...
   uint32_t* cq_jj = cq_doc + cq_cap;                // ... and the query position of the list each was met in (later: the verdict)
   uint32_t* rowtab = cq_jj + cq_cap;                // the row table: {first chunk, live lanes} per row (8-byte aligned) ...
-  uint8_t* rowlist = (uint8_t*)(rowtab + 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL));   // ... and the list (query position) of each row
-  uint32_t* dummy_w = rowtab + 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2;   // then one
+  uint8_t* rowlist = (uint8_t*)(rowtab + 2 * (L::rowtab_cap + 2 * SG_UNROLL));   // ... and the list (query position) of each row
+  uint32_t* dummy_w = rowtab + 2 * (L::rowtab_cap + 2 * SG_UNROLL) + (L::rowtab_cap + 2 * SG_UNROLL + 7) / 8 * 2;   // then one
   const uint32_t dummy_lane = (uint32_t)(uintptr_t)(lds_u32*)(dummy_w + lane);   // private dummy counter word per lane
   // the query's terms as an LDS hash (linear probing; an occurrence = an entry, so a repeated term sits in consecutive
   // probe slots): what a candidate's own term list (forward index) is matched against
   uint32_t* qh_key = dummy_w + 64;
-  uint8_t* qh_pos = (uint8_t*)(qh_key + SG_QH);     // query position of the entry
+  uint8_t* qh_pos = (uint8_t*)(qh_key + L::qh);     // query position of the entry
   // the repeated-term path (documents that repeat a term: rare) borrows row table + dummies + hash — all idle while
   // candidates are emitted — and rebuilds the hash afterwards
   uint32_t* dup_scratch = rowtab;
-  static_assert(SG_DUP_SCRATCH <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64 + SG_QH + SG_QH / 4,
-                "dup scratch must fit row table + dummies + hash");   // (the epoch ring behind the hash is NOT part of it)
-  uint32_t* ep_ring = qh_key + SG_QH + SG_QH / 4;   // [SG_EPOCHS][6] streamed-list mask (128 bits over query positions) + docID range of a group pass
+  uint32_t* ep_ring = qh_key + L::qh + L::qh / 4;   // [SG_EPOCHS][6] streamed-list mask (128 bits over query positions) + docID range of a group pass
   // {k-th best score the tile's thresholds were tightened against (2 words), first segment still to come, -}: in LDS, not
   // in scalar registers — the stream loop has none to spare
   uint32_t* tile_state = ep_ring + SG_EPOCH_WORDS * SG_EPOCHS;
@@ -838,12 +863,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; break; }
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; break; }
   auto build_qhash = [&]() {
-    for (uint32_t i = lane; i < SG_QH; i += 64) qh_key[i] = kNoTerm;
+    for (uint32_t i = lane; i < L::qh; i += 64) qh_key[i] = kNoTerm;
     __syncthreads();
     for (int i = lane; i < A; i += 64) {
       const uint32_t x = term[i];
       if (x == kNoTerm) continue;
-      for (uint32_t h = d_qhash(x);; h = d_qnext(h))
+      for (uint32_t h = d_qhash<L::qh>(x);; h = d_qnext<L::qh>(h))
         if (atomicCAS(qh_key + h, kNoTerm, x) == kNoTerm) { qh_pos[h] = (uint8_t)i; break; }
     }
     __syncthreads();
@@ -872,7 +897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
   const uint4* __restrict__ post4 = (const uint4*)ix.postings;
   const int a_rounds = (A + 63) >> 6;                          // 1 or 2 (A <= SG_MAX_A = 128)
-  const int wt_max = min(SG_TILE_MAX, SG_ROWS_CAP / A - 1);   // A <= 128 -> >= 7
+  const int wt_max = min(SG_TILE_MAX, (int)L::rows_cap / A - 1);   // A <= 128 -> >= 7
   const uint32_t max_buckets = cnt_words * 4u;                 // u8 mode
 
   uint32_t pushed = 0;                                         // parts of this query queued for the second launch
@@ -1049,10 +1074,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // table's LDS (idle outside the stream): max over (doc, list) per slot; a slot two documents share favours the
         // larger docID, the other is simply verified as usual.
         unsigned long long* dh = (unsigned long long*)rowtab;
-        static_assert(2 * 128 <= 2 * (SG_ROWTAB_CAP + 2 * SG_UNROLL) + (SG_ROWTAB_CAP + 2 * SG_UNROLL + 7) / 8 * 2 + 64, "dedup table must fit row table + dummies");
-        dh[lane] = 0ull; dh[64 + lane] = 0ull;
+        dh[lane] = 0ull; if (64 + lane < L::dedup) dh[64 + lane] = 0ull;
         __syncthreads();
-        const uint32_t slot = (my_doc * 0x9E3779B1u) >> 25;
+        const uint32_t slot = (((my_doc * 0x9E3779B1u) >> 25) * (uint32_t)L::dedup) >> 7;
         const unsigned long long mine = ((unsigned long long)my_doc << 32) | (unsigned long long)(my_jj & 0xFFu);
         if ((uint32_t)lane < n) __hip_atomic_fetch_max(dh + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
@@ -1103,7 +1127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           uint32_t mult = 0;
           bool lt = false;
           if (x != kNoTerm) {
-            for (uint32_t h = d_qhash(x);; h = d_qnext(h)) {
+            for (uint32_t h = d_qhash<L::qh>(x);; h = d_qnext<L::qh>(h)) {
               const uint32_t kx = qh_key[h];
               if (kx == kNoTerm) break;
               if (kx == x) {
@@ -1391,7 +1415,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the running
         // row number where they start (pr, wave scan) and writes their descriptors {first chunk, live lanes,
         // list} to the LDS row table; the stream loop then needs one uniform LDS read per row — no ballots,
-        // no VALU->SALU->readlane dependency chains.  Tables larger than SG_ROWTAB_CAP are done in windows.
+        // no VALU->SALU->readlane dependency chains.  Tables larger than L::rowtab_cap are done in windows.
         uint32_t nr[2], pr[2];
         uint32_t n_rows = 0;
 #pragma unroll
@@ -1403,8 +1427,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           n_rows += readlane(incl, 63);
         }
         uint2* rowtab2 = (uint2*)rowtab;
-        for (uint32_t w0 = 0; w0 < n_rows && !DBG_SKIP(512u); w0 += SG_ROWTAB_CAP) {
-          const uint32_t wn = min((uint32_t)SG_ROWTAB_CAP, n_rows - w0);
+        for (uint32_t w0 = 0; w0 < n_rows && !DBG_SKIP(512u); w0 += L::rowtab_cap) {
+          const uint32_t wn = min(L::rowtab_cap, n_rows - w0);
           __syncthreads();
 #pragma unroll
           for (int r = 0; r < 2; r++) {
@@ -1500,14 +1524,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
                 flag = now >= (uint32_t)Teff;
               }
-              const uint64_t m = ballot(flag);
-              if (!m) continue;
-              const uint32_t cnt_f = popc64(m);
-              DBG_COUNT(3, cnt_f)
-              if (qn + cnt_f > cq_cap) flush_queue();
-              const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-              if (flag) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i | ep_tag; }
-              qn += cnt_f;
+              const uint64_t m_all = ballot(flag);
+              if (!m_all) continue;
+              // (the queue may hold fewer than 64 entries — never fewer than 32: the two halves of the wave go in turn)
+#pragma nounroll
+              for (int half = 0; half < 2; half++) {
+                const uint64_t m = half ? (m_all >> 32) << 32 : m_all & 0xFFFFFFFFull;
+                if (!m) continue;
+                const uint32_t cnt_f = popc64(m);
+                DBG_COUNT(3, cnt_f)
+                if (qn + cnt_f > cq_cap) flush_queue();
+                const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (flag && ((m >> lane) & 1ull)) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i | ep_tag; }
+                qn += cnt_f;
+              }
             }
           }
         }
@@ -1583,6 +1613,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (!kLM && !a.autocomplete && a.fill_stat && lane == 0 && (qi & 31u) == 0u) {
     atomicAdd(a.fill_stat + 1, 1u);
     if (n == k) atomicAdd(a.fill_stat, 1u);
+    if (n) atomicAdd(a.fill_stat + 2, n);
   }
   if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 2] = (uint32_t)(qe - qb); out_ids[k - 3] = qi; out_ids[k - 4] = (uint32_t)qb; }
   PH(7)
@@ -1721,11 +1752,13 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
   for (uint32_t i = threadIdx.x; i < n; i += 64) out_vals[i] = v[i];
 }
 
-#define sg_search_kernel sg_search_kernel_t<false, false, false>
-#define sg_search_kernel_tight sg_search_kernel_t<false, false, true>
-#define sg_parts_kernel sg_search_kernel_t<true, false, false>
-#define sg_parts_kernel_tight sg_search_kernel_t<true, false, true>
-#define sg_lm_kernel sg_search_kernel_t<false, true, false>
+#define sg_search_kernel sg_search_kernel_t<false, false, false, false>
+#define sg_search_kernel_slim sg_search_kernel_t<false, false, false, true>
+#define sg_search_kernel_tight sg_search_kernel_t<false, false, true, false>
+#define sg_parts_kernel sg_search_kernel_t<true, false, false, false>
+#define sg_parts_kernel_tight sg_search_kernel_t<true, false, true, false>
+#define sg_lm_kernel sg_search_kernel_t<false, true, false, false>
+#define sg_lm_kernel_slim sg_search_kernel_t<false, true, false, true>
 
 }  // namespace sg
 
