@@ -120,7 +120,7 @@ def test_cars_all_lines_as_queries(cars_lines, tighten):
     the rows where the reference returns a document twice (documents that repeat a term).  With and
     without threshold tightening (its own kernel instantiation; 2 = picked per launch from what recent queries did)."""
     from suggest_amd import NGramIndex
-    gpu = NGramIndex(cars_lines, _desc(CARS_DESC)).tune(SG_TIGHTEN=tighten)
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC)).tune(SG_TIGHTEN=tighten, SG_ROOMY=(2, 0, 1)[tighten])    # (small queue + slim tables with tightening on)
     ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
     queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]] + [l.lower()[:-2] for l in cars_lines[::11]]
     qb, qo = oracle.pack_strings(queries)
@@ -291,9 +291,10 @@ def test_saturating_bucket_and_candidate_overflow():
     assert np.array_equal(ids[valid], oi[valid])
 
 
-@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9", SG_SPLIT_CHUNKS="0", SG_TIGHTEN="1"),
-                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12", SG_SPLIT_CHUNKS="8", SG_TIGHTEN="0"),
-                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10", SG_SPLIT_CHUNKS="200", SG_TIGHTEN="1")])
+@pytest.mark.parametrize("knobs", [dict(SG_T_FLOOR="1", SG_FILTER_LEVEL="0", SG_LOG2_CNT="9", SG_SPLIT_CHUNKS="0", SG_TIGHTEN="1", SG_ROOMY="0"),
+                                   dict(SG_T_FLOOR="3", SG_FILTER_LEVEL="3", SG_LOG2_CNT="12", SG_SPLIT_CHUNKS="8", SG_TIGHTEN="0", SG_ROOMY="1"),
+                                   dict(SG_T_FLOOR="100", SG_FILTER_LEVEL="1", SG_LOG2_CNT="10", SG_SPLIT_CHUNKS="200", SG_TIGHTEN="1", SG_ROOMY="1"),
+                                   dict(SG_T_FLOOR="8", SG_FILTER_LEVEL="4", SG_LOG2_CNT="11", SG_TIGHTEN="0", SG_ROOMY="0")])
 def test_results_do_not_depend_on_tuning_knobs(monkeypatch, knobs):
     """The lossy counters are only a filter (every flagged doc is verified exactly), so list-skipping depth,
     bucket-table strictness and counter-array size must not change a single output bit (DESIGN.md §4 knobs)."""
