@@ -23,8 +23,8 @@ for p in sorted(glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=Tru
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
         name = r.get("Kernel_Name", "")
-        if "sg_search" in name:      # the batch kernel <false,false>, the parts kernel <true,false>, the LM kernel <false,true>
-            kind = "parts " if "<true" in name else "lm    " if "false, true" in name else "search"
+        if "sg_search" in name:      # <kParts, kLM, kTight, kSlim>: the batch kernel <false,false,..>, the parts kernel <true,..>, the LM kernel <false,true,..>
+            kind = "parts " if "<true" in name else "lm    " if "<false, true" in name else "search"
             acc[(kind, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kind, k), v in sorted(acc.items()):
         print("%s %-28s per-dispatch avg %.6g (n=%d)" % (kind, k, sum(v) / len(v), len(v)))
