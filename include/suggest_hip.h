@@ -221,7 +221,7 @@ int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, 
 int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* out);
 
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
- * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
+ * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
 int sg_index_tune(sg_index* index, const char* knob, int value);
 
 /* Tokens of `text` as the index sees them, one packed 64-bit term key each (DESIGN.md §Term keys);

@@ -1739,6 +1739,45 @@ __global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
   if (lane == 0) p.out_counts[i] = m;
 }
 
+// Workgroups start in index order and one wavefront owns one query, so a launch ends when its last-started heavy query
+// does.  A query's work grows with its length (more lists, a wider window of segments; for autocomplete it is the short
+// prefixes that match the most): a counting sort by byte length gives the launch its queries heaviest first
+// (BatchArgs::q_sel).  Two small launches over 1024-query blocks — a single workgroup spent 77 us on the LDS atomics of
+// 65 536 queries: (1) lengths histogram, block-local then added to the global one; (2) every block reserves, per length,
+// a run behind the lengths before it and scatters its queries there.  Which of two equally long queries comes first is
+// left to the atomics; rows are written by query index, so the results do not depend on it.
+// ctl: [0] = n_q (BatchArgs::q_sel_n), [4 .. 260) histogram, [260 .. 516) cursors — zeroed by the host before (1).
+#define SG_ORDER_CTL_WORDS 516
+__device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, uint32_t i, int shortest_first) {
+  const uint32_t len = (uint32_t)min((unsigned long long)(q_offs[i + 1] - q_offs[i]), 255ull);
+  return shortest_first ? len : 255u - len;
+}
+__global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, uint32_t n_q, int shortest_first, uint32_t* ctl) {
+  __shared__ uint32_t hist[256];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
+  if (tid < 256u) hist[tid] = 0u;
+  __syncthreads();
+  if (i < n_q) atomicAdd(&hist[d_order_bin(q_offs, i, shortest_first)], 1u);
+  __syncthreads();
+  if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
+  if (i == 0u) ctl[0] = n_q;
+}
+__global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl) {
+  __shared__ uint32_t hist[256], start[256];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
+  if (tid < 256u) hist[tid] = 0u;
+  __syncthreads();
+  const uint32_t bin = i < n_q ? d_order_bin(q_offs, i, shortest_first) : 0u;
+  if (i < n_q) atomicAdd(&hist[bin], 1u);
+  if (tid < 256u) start[tid] = ctl[4 + tid];
+  __syncthreads();
+  if (tid == 0u) { uint32_t run = 0; for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = start[b]; start[b] = run; run += c; } }
+  __syncthreads();
+  if (tid < 256u) { const uint32_t c = hist[tid]; hist[tid] = c ? start[tid] + atomicAdd(ctl + 260 + tid, c) : 0u; }
+  __syncthreads();
+  if (i < n_q) order[atomicAdd(&hist[bin], 1u)] = i;
+}
+
 // test hook (sg_debug_pairsort): the device's restatement of Go 1.14 sort.Sort on arbitrary keys — a differential fuzz
 // compares it with the oracle's and with a third, independent restatement (tests/gosort.py)
 __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys, uint32_t n, uint32_t* out_vals) {

@@ -120,6 +120,31 @@ def test_host_buffer_callers_during_index_churn(small):
     assert calls[0] > 100
 
 
+def test_heaviest_first_query_order_changes_nothing(small):
+    """Batches of >= 8192 queries run in a counting-sort order by length (longest first; autocomplete: shortest first —
+    query_order_kernels in engine.hip); rows are written by query index, so the output must be the same byte for byte,
+    including empty queries and queries longer than the sort's 255-byte last bin."""
+    from suggest_amd import synth
+    gpu, ora, qb, qo = small
+    base = synth.unpack(qb, qo)
+    queries = (base * 3)[:12000]
+    queries[17] = b""
+    queries[4242] = b"x" * 300
+    queries[9001] = base[5] * 9
+    qb2, qo2 = oracle.pack_strings(queries)
+    out = {}
+    for order in (0, 1):
+        gpu.tune(SG_ORDER=order)
+        out[order] = (gpu.suggest_batch(blob=qb2, offs=qo2, metric="cosine", similarity=0.45, k=7),
+                      gpu.autocomplete_batch(blob=qb2, offs=qo2, limit=6))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    want = list(ora.suggest_batch(qb2, qo2, "cosine", 0.45, 7)[:3])
+    assert out[1][0][2][4242] == 0xFFFFFFFD          # SG_COUNT_TOO_LONG: 300 runes are past the device's 144 (DESIGN.md §6)
+    want[2] = want[2].copy(); want[2][4242] = 0xFFFFFFFD
+    assert_same(out[1][0], want)
+
+
 def test_single_query_load_generator():
     """tools/single_query_load (C++, through the C ABI): N threads of blocking sg_suggest_one calls; checks every answer
     against the batch call and reports the rate (the number itself is not asserted here: DESIGN.md)"""
