@@ -228,7 +228,13 @@ def main():
             n_s = int(min(n_q, max(probe, probe / max(dt, 1e-6) * 12)))
         (oi, os_, oc, used), dt = timed(n_s, cores)
         note = "C++ restatement of the Go path (oracle/), OpenMP across queries; the Go reference is not runnable here (no toolchain)"
-        cpu = {"value": n_s / dt, "unit": "queries/s", "cores": used, "kind": "port",
+        quota = None
+        try:      # (a container's CPU quota: the threads above share this many cores)
+            q_us, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q_us == "max" else float(q_us) / float(period)
+        except (OSError, ValueError):
+            pass
+        cpu = {"value": n_s / dt, "unit": "queries/s", "cores": used, "cpu_quota_cores": quota, "kind": "port",
                "sample": "first %d queries of batch 0, same %d-string dictionary; %s" % (n_s, args.dict_size, note)}
         n_1 = int(max(16, min(n_s, cpu["value"] / max(used, 1) * 6)))      # ~6 s on one thread
         (_, _, _, used1), dt1 = timed(n_1, 1)
@@ -275,7 +281,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "sg_search_kernel", "kernel_ms_avg": avg_ms,
                 "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
                 "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
-                "note": "achieved = algorithmic (ScanCount-volume) bytes / kernel time, SURVEY.md 8d; wire_* = PMC traffic / the same time"}
+                "note": "achieved = algorithmic (ScanCount-volume) bytes / kernel time, SURVEY.md 8d; wire_* = PMC traffic / the same time; "
+                        "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
+                        "queries and the two query-ordering launches (~10 us) before them"}
         if traffic:
             roof["wire_gbps"] = traffic / (avg_ms * 1e-3) / 1e9
             roof["wire_frac"] = roof["wire_gbps"] / HBM_PEAK_GBS
