@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 KNOBS = (("SG_LOG2_CNT", ["9", "10", "11", "12"]), ("SG_T_FLOOR", ["2", "4", "10", "30"]), ("SG_FILTER_LEVEL", ["0", "2", "3", "4", "6", "7"]),
-         ("SG_SPLIT_CHUNKS", ["0", "1", "8", "65536"]), ("SG_TIGHTEN", ["0", "1", "1", "2"]), ("SG_ROOMY", ["0", "1", "2"]))
+         ("SG_SPLIT_CHUNKS", ["0", "1", "8", "65536"]), ("SG_TIGHTEN", ["0", "1", "1", "2"]), ("SG_ROOMY", ["0", "1", "2"]), ("SG_ORDER", ["0", "1", "2", "16"]))
 
 
 def make_trial(seed, scale=1):
