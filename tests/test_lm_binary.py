@@ -144,10 +144,12 @@ def test_predict_hand_derived_vectors_gpu():
 
 
 @pytest.mark.gpu
-def test_predict_production_ids_vs_oracle_on_a_synthetic_model(tmp_path):
+@pytest.mark.parametrize("slices", ["1", "3"])
+def test_predict_production_ids_vs_oracle_on_a_synthetic_model(tmp_path, monkeypatch, slices):
     """the device pipeline (Next -> LM-ranked autocomplete -> selection -> fuzzy top-up -> merge / stable re-rank) against
     the oracle on a model in the reference's binary format: ties are broken by word id, so the id order matters"""
     import sys
+    monkeypatch.setenv("SG_SPELL_SLICES", slices)      # (big batches go through in two slices on two streams: the same path, forced)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import make_synthetic_lm
     from suggest_amd.spell import LanguageModel, SpellChecker
