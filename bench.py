@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — fuzzy queries/sec of the MI355X engine on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W [--config headline|cfg2|cfg3|cfg4|cfg5]
-  (N=1 directly; N>1 under torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config headline|cfg2|cfg3|cfg4|cfg5] [--mode procs|replicas]
 
 A "step" is one pass of the hot path (tokenise -> posting lookup -> T-occurrence count -> score -> top-k)
 over one batch of synthetic queries per GPU, inputs already resident in HBM.  The default workload is the
@@ -10,21 +9,35 @@ one BASELINE.json's `metric` is quoted on: 10M synthetic strings (len 8-32 over 
 Jaccard>=0.5, k=10, 65,536 edited queries per GPU and step.  --config selects the other BASELINE.json
 configs (cfg2: 1M strings; cfg3: Cosine>=0.4 k=20; cfg4: q=2 Dice>=0.5; cfg5: the spellchecker caller).
 Steps rotate over --batches (default 4) distinct query batches, all resident before the timed region.
-Weak scaling: every rank holds a full index replica and its own batches; the only collective is the
-optional gather of the k*(u32,f64) result rows over RCCL.
+
+N > 1 (weak scaling: every GPU holds a full index replica and gets its own batches; no data-path collective):
+  --mode procs (default)  one process per GPU under torch.distributed.run.  Started WITHOUT a launcher
+                          (`python bench.py --gpus 8`, no WORLD_SIZE) the script re-executes itself under
+                          `python -m torch.distributed.run --nproc-per-node N` — it never measures one GPU and
+                          calls it N.  Rank 0 then also measures the single-process replica path below and
+                          reports it as `replicas_mode`, beside the process-per-GPU number.
+  --mode replicas         ONE process: sg_index_replicate over N devices + sg_suggest_batch_multi on host
+                          buffers (a worker thread per replica) — what a Go host behind the C ABI runs.
+                          PCIe-inclusive by construction, so its line says so (`config.pcie_inclusive`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline      achieved = ALGORITHMIC bytes per launch (sg_suggest_algorithmic_bytes) / the search
-                kernel's average launch duration (HIP events on the launch stream); traffic = HBM bytes per launch
-                from a rocprofv3 --pmc FETCH_SIZE pass over this workload — live in a child process (--traffic), else the
-                committed run in profiles/traffic.json — with
-                wire_gbps / wire_frac = that traffic over the same duration
+  roofline      achieved / frac = MEASURED HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x 1024 x 2, the gfx950
+                correction of MI355X_MICROARCH.md; live child pass of the same workload, else the committed figure in
+                profiles/traffic.json) / the search kernel's average launch duration (HIP events on the launch stream)
+                / the 8 TB/s peak — a physical fraction, always <= 1.
+                effective_gbps / effective_frac = ALGORITHMIC bytes per launch (every posting of every
+                query term in every admissible segment once, sg_suggest_algorithmic_bytes) over the same duration: the
+                rate a full ScanCount scan would need to answer as fast.  List skipping and compressed postings read
+                less than that volume, so this figure may exceed the peak; it is not a bandwidth.
   cpu_baseline  the CPU oracle — a C++ restatement of the Go path, kind "port" — on this host: all hardware
                 threads, and one thread (`one_thread`), each on a bounded sample of the same batch
+  configs       (default run only) sub-records for BASELINE.json's cfg2 / cfg3 / cfg4 measured the same way in the same
+                process: value, kernel ms, both fractions, bit-exactness against the oracle on a sample
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -40,15 +53,19 @@ CONFIGS = {   # BASELINE.json `configs` (cfg1 is the CPU-only plumbing case: tes
     "cfg3": dict(dict_size=10_000_000, queries=65536, ngram=3, metric="cosine", similarity=0.4, topk=20),
     "cfg4": dict(dict_size=10_000_000, queries=16384, ngram=2, metric="dice", similarity=0.5, topk=10),
 }
+WORKLOAD_KEYS = ("dict_size", "queries", "ngram", "metric", "similarity", "topk")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS) + ["cfg5"],
                     help="BASELINE.json config (default: the one the metric is quoted on); explicit flags below override it")
+    ap.add_argument("--mode", default="procs", choices=["procs", "replicas"],
+                    help="N>1: a process per GPU (torch.distributed.run; self-spawned when no launcher is present) or ONE "
+                         "process driving a replica per GPU through sg_suggest_batch_multi")
     ap.add_argument("--dict-size", type=int, default=None)
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU per step")
     ap.add_argument("--ngram", type=int, default=None)
@@ -63,70 +80,122 @@ def main():
                          "built) or on the host (sg_index_build, then uploaded); same arrays either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
+    ap.add_argument("--sub-configs", default="auto",
+                    help="comma list of BASELINE configs measured after the main one and reported under `configs` "
+                         "(auto = cfg2,cfg3,cfg4 for the plain default run at N=1, none otherwise; 'none' = off)")
     ap.add_argument("--gather", action="store_true",
                     help="N>1: include the optional RCCL all_gather of the k*(u32,f64) result rows in every timed step "
                          "(default: results stay sharded — the path has no data-path collective; one untimed gather validates RCCL)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a rocprofv3 --pmc run, reported as roofline.traffic (default: the figure "
-                         "recorded in profiles/traffic.json for this exact workload, measured with tools/pmc_run.sh)")
+                    help="HBM bytes per launch from a rocprofv3 --pmc run, reported as roofline.traffic (default: measured live)")
     ap.add_argument("--require-traffic", action="store_true", help="exit non-zero when no traffic figure could be had for the workload")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: live = a rocprofv3 --pmc FETCH_SIZE pass over this same workload in a child process "
                          "(after the timed region; N=1 only); file = the committed measurement in profiles/traffic.json; "
                          "auto = live when rocprofv3 is there, else file")
-    args = ap.parse_args()
-    if args.config == "cfg5":
-        import bench_spell
-        return bench_spell.main(args)
-    preset = CONFIGS[args.config]
-    for key, val in preset.items():
+    args = ap.parse_args(argv)
+    args.explicit_workload = any(getattr(args, k) is not None for k in WORKLOAD_KEYS)
+    return args
+
+
+def apply_preset(args, name):
+    for key, val in CONFIGS[name].items():
         if getattr(args, key) is None:
             setattr(args, key, val)
 
-    import numpy as np
+
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `python -m torch.distributed.run ... bench.py <same args>`."""
     import torch
-    import torch.distributed as dist
-    from suggest_amd import IndexDescription, NGramIndex, synth
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and os.environ.get("SG_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node — refusing to measure fewer GPUs than asked for"
+                         % (args.gpus, have))
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: re-executing as %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    # test hooks (1-GPU box): SG_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0, SG_BENCH_BACKEND=gloo avoids RCCL's
-    # one-rank-per-GPU rule — exercises the N>1 control flow (barriers, max-over-ranks, per-rank batches), not the links
-    if os.environ.get("SG_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
-    def log(*a):
-        if rank == 0:
+class Env:
+    """rank / world / device of this process"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if args.mode == "procs" else 1
+        if args.mode == "procs" and self.world != args.gpus:
+            raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+        # test hooks (1-GPU box): SG_BENCH_SINGLE_DEVICE=1 puts every rank / replica on GPU 0, SG_BENCH_BACKEND=gloo avoids RCCL's
+        # one-rank-per-GPU rule — exercises the N>1 control flow (barriers, max-over-ranks, per-rank batches), not the links
+        self.single_device = os.environ.get("SG_BENCH_SINGLE_DEVICE") == "1"
+        if self.single_device:
+            self.local_rank = 0
+        self.backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+                # (waiting for rank 0's single-process replica leg must not keep a spinning RCCL kernel on every GPU)
+                self.cpu_group = dist.new_group(backend="gloo")
+            else:
+                dist.init_process_group(self.backend)
+                self.cpu_group = None
+
+    def log(self, *a):
+        if self.rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
-    # ---- workload -------------------------------------------------------------------------
-    desc_kw = dict(synth.DESCRIPTION, ngram_size=args.ngram)
-    k, n_q, n_b = args.topk, args.queries, max(1, args.batches)
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+
+_DICT_CACHE = {}
+
+
+def get_dict(size, variant):
+    from suggest_amd import synth
+    key = (size, variant)
+    if key not in _DICT_CACHE:
+        _DICT_CACHE.clear()                                   # (one 10M dictionary at a time: ~200 MB)
+        _DICT_CACHE[key] = synth.make_dict(size, seed=1, skewed="skewed" in variant, families=3 if "families" in variant else 0)
+    return _DICT_CACHE[key]
+
+
+def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traffic_mode="auto", replicas_leg=False):
+    """One workload `w` (dict of WORKLOAD_KEYS + variant) on this rank's GPU -> the record (rank 0) or None."""
+    import numpy as np
+    torch, dist = env.torch, env.dist
+    from suggest_amd import IndexDescription, NGramIndex, synth
+    rank, world, dev, log = env.rank, env.world, env.dev, env.log
+    desc_kw = dict(synth.DESCRIPTION, ngram_size=w["ngram"])
+    k, n_q, n_b = w["topk"], w["queries"], max(1, args.batches)
     t0 = time.time()
-    blob, offs = synth.make_dict(args.dict_size, seed=1, skewed="skewed" in args.dict_variant,
-                                 families=3 if "families" in args.dict_variant else 0)
+    blob, offs = get_dict(w["dict_size"], w["variant"])
     # batch b of rank r = queries [(r * n_b + b) * n_q, ...) of one deterministic stream (seed 2)
     batches = [synth.make_queries(n_q, blob, offs, seed=2, start=(rank * n_b + b) * n_q) for b in range(n_b)]
-    log("dict %d strings + %d batches of %d queries generated in %.1fs" % (args.dict_size, n_b, n_q, time.time() - t0))
+    log("[%s] dict %d strings + %d batches of %d queries generated in %.1fs" % (w["name"], w["dict_size"], n_b, n_q, time.time() - t0))
     t0 = time.time()
-    index = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc_kw), device=local_rank, build=args.build)
+    index = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc_kw), device=env.local_rank, build=args.build)
     st = index.stats()
-    log("index built (%s) + uploaded in %.1fs: %s" % (args.build, time.time() - t0, st))
-    alg = [index.algorithmic_bytes(qb, qo, args.metric, args.similarity, k) for qb, qo in batches]
+    log("[%s] index built (%s) + uploaded in %.1fs: %s" % (w["name"], args.build, time.time() - t0, st))
+    alg = [index.algorithmic_bytes(qb, qo, w["metric"], w["similarity"], k) for qb, qo in batches]
 
     d_q = [torch.from_numpy(qb).to(dev) if qb.size else torch.zeros(1, dtype=torch.uint8, device=dev) for qb, _ in batches]
     d_offs = [torch.from_numpy(qo.view(np.int64)).to(dev) for _, qo in batches]
@@ -140,7 +209,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def step(b):
-        index.suggest_batch_device(d_q[b].data_ptr(), d_offs[b].data_ptr(), n_q, args.metric, args.similarity, k,
+        index.suggest_batch_device(d_q[b].data_ptr(), d_offs[b].data_ptr(), n_q, w["metric"], w["similarity"], k,
                                    d_ids[b].data_ptr(), d_sc[b].data_ptr(), d_cnt[b].data_ptr(), stream=stream.cuda_stream)
 
     def gather(b, force=False):
@@ -149,28 +218,22 @@ def main():
             dist.all_gather_into_tensor(g_sc, d_sc[b])
             dist.all_gather_into_tensor(g_cnt, d_cnt[b])
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i % n_b)
         gather(i % n_b)
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    env.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t_start = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         ev[i][0].record(stream)
         step(i % n_b)
         ev[i][1].record(stream)
         gather(i % n_b)
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    alg_timed = float(np.mean([alg[i % n_b] for i in range(args.steps)]))       # algorithmic bytes per launch, timed launches
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    alg_timed = float(np.mean([alg[i % n_b] for i in range(steps)]))       # algorithmic bytes per launch, timed launches
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if env.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -185,47 +248,61 @@ def main():
             log("result gather over RCCL failed: %r" % (exc,))
             gather_ok = False
 
-    for b in range(min(n_b, args.steps + args.warmup), n_b):      # (batches the run never reached)
-        step(b)
+    reached = {i % n_b for i in range(warmup)} | {i % n_b for i in range(steps)}
+    for b in range(n_b):                                 # (batches the run never reached)
+        if b not in reached:
+            step(b)
     torch.cuda.synchronize(dev)
     ids = [x.cpu().numpy().view(np.uint32) for x in d_ids]
     sc = [x.cpu().numpy() for x in d_sc]
     cnt = [x.cpu().numpy().view(np.uint32) for x in d_cnt]
 
     # ---- the host-buffer entry point (what a cgo caller uses): PCIe-inclusive, never the headline value ----
-    host_rate = None
-    if rank == 0 and world == 1:
+    host = None
+    if rank == 0 and world == 1 and host_rate:
         qb, qo = batches[0]
-        index.suggest_batch(blob=qb, offs=qo, metric=args.metric, similarity=args.similarity, k=k)
+        index.suggest_batch(blob=qb, offs=qo, metric=w["metric"], similarity=w["similarity"], k=k)
         reps = 3
         t0 = time.perf_counter()
         for _ in range(reps):
-            h_ids, h_sc, h_cnt = index.suggest_batch(blob=qb, offs=qo, metric=args.metric, similarity=args.similarity, k=k)
-        host_rate = reps * n_q / (time.perf_counter() - t0)
+            h_ids, h_sc, h_cnt = index.suggest_batch(blob=qb, offs=qo, metric=w["metric"], similarity=w["similarity"], k=k)
+        host = reps * n_q / (time.perf_counter() - t0)
         if not (np.array_equal(h_cnt, cnt[0]) and np.array_equal(h_ids, ids[0])):
             raise SystemExit("sg_suggest_batch (host buffers) and sg_suggest_batch_device disagree")
+
+    # ---- one process, a replica per GPU, sg_suggest_batch_multi (rank 0, after the timed region; the other ranks wait) ----
+    replicas = None
+    if replicas_leg and rank == 0:
+        try:
+            replicas = replicas_measure(env, args, index, w, batches, ids, cnt, n_gpus=args.gpus, steps=max(4, min(steps, 10)), warmup=2)
+        except Exception as exc:
+            log("replicas leg failed: %r" % (exc,))
+            replicas = {"error": repr(exc)}
+    if replicas_leg and world > 1:
+        dist.barrier(group=env.cpu_group)
 
     # ---- CPU baseline: the oracle (restatement of the Go path) on this host, rank 0, N=1 only ----
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu_baseline:
         import oracle
         t0 = time.time()
         ora = oracle.OracleIndex(blob=blob, offs=offs, **desc_kw)
-        log("oracle index built in %.1fs" % (time.time() - t0))
+        log("[%s] oracle index built in %.1fs" % (w["name"], time.time() - t0))
         cores = os.cpu_count() or 1
         qb, qo = batches[0]
 
         def timed(n, threads):
             t0 = time.perf_counter()
-            res = ora.suggest_batch(qb[:int(qo[n])], qo[:n + 1], args.metric, args.similarity, k, threads=threads)
+            res = ora.suggest_batch(qb[:int(qo[n])], qo[:n + 1], w["metric"], w["similarity"], k, threads=threads)
             return res, time.perf_counter() - t0
 
+        budget = 12.0 if cpu_baseline is True else float(cpu_baseline)       # seconds of wall time for the all-threads sample
         n_s = min(args.cpu_sample or n_q, n_q)
-        if not args.cpu_sample:            # calibrate so that the timed sample is ~10-15 s of wall time
-            probe = min(n_q, 2048)
+        if not args.cpu_sample:
+            probe = min(n_q, 2048 if budget >= 8 else 512)
             _, dt = timed(probe, cores)
-            n_s = int(min(n_q, max(probe, probe / max(dt, 1e-6) * 12)))
+            n_s = int(min(n_q, max(probe, probe / max(dt, 1e-6) * budget)))
         (oi, os_, oc, used), dt = timed(n_s, cores)
         note = "C++ restatement of the Go path (oracle/), OpenMP across queries; the Go reference is not runnable here (no toolchain)"
         quota = None
@@ -235,95 +312,237 @@ def main():
         except (OSError, ValueError):
             pass
         cpu = {"value": n_s / dt, "unit": "queries/s", "cores": used, "cpu_quota_cores": quota, "kind": "port",
-               "sample": "first %d queries of batch 0, same %d-string dictionary; %s" % (n_s, args.dict_size, note)}
-        n_1 = int(max(16, min(n_s, cpu["value"] / max(used, 1) * 6)))      # ~6 s on one thread
+               "sample": "first %d queries of batch 0, same %d-string dictionary; %s" % (n_s, w["dict_size"], note)}
+        n_1 = int(max(16, min(n_s, cpu["value"] / max(used, 1) * budget / 2)))      # ~budget/2 s on one thread
         (_, _, _, used1), dt1 = timed(n_1, 1)
         cpu["one_thread"] = {"value": n_1 / dt1, "unit": "queries/s", "cores": used1, "sample": "first %d queries of batch 0" % n_1}
         valid = np.arange(k)[None, :] < np.minimum(oc, k)[:, None]
         same = np.array_equal(cnt[0][:n_s], oc) and np.array_equal(ids[0][:n_s][valid], oi[valid]) and \
             np.array_equal(sc[0][:n_s].view(np.uint64)[valid], os_.view(np.uint64)[valid])
         parity = {"checked_queries": int(n_s), "bit_exact": bool(same)}
-        log("cpu baseline %.0f q/s on %d threads, %.0f q/s on one; GPU result bit-exact vs oracle on the sample: %s"
-            % (cpu["value"], used, cpu["one_thread"]["value"], same))
+        log("[%s] cpu baseline %.0f q/s on %d threads, %.0f q/s on one; GPU result bit-exact vs oracle on the sample: %s"
+            % (w["name"], cpu["value"], used, cpu["one_thread"]["value"], same))
+        del ora
 
-    key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (args.dict_size, n_q, args.ngram, args.metric, args.similarity, k, args.dict_variant)
-    traffic, traffic_src = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes else None)
-    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)     # (no profiler inside a profiler)
-    if traffic is None and args.traffic in ("auto", "live") and rank == 0 and world == 1 and not (under_profiler and args.traffic == "auto"):
-        traffic, traffic_src = _live_traffic(args, log)
-        if traffic is None and args.traffic == "live":
+    key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (w["dict_size"], n_q, w["ngram"], w["metric"], w["similarity"], k, w["variant"])
+    traffic, traffic_src = args.traffic_bytes if w["name"] == args.config else None, None
+    if traffic:
+        traffic_src = "--traffic-bytes"
+    under_profiler = any(kk.startswith(("ROCPROF", "ROCP_")) for kk in os.environ)     # (no profiler inside a profiler)
+    if traffic is None and traffic_mode in ("auto", "live") and rank == 0 and world == 1 and not (under_profiler and traffic_mode == "auto"):
+        traffic, traffic_src = _live_traffic(args, w, log)
+        if traffic is None and traffic_mode == "live":
             raise SystemExit("live PMC pass failed: " + str(traffic_src))
-    if traffic is None and args.traffic != "none":      # the committed measurement of this workload
+        if traffic is None:
+            log("live PMC pass unavailable: %s" % (traffic_src,))
+    if traffic is None and traffic_mode != "none":      # the committed measurement of this workload
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
             if rec:
-                traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
+                traffic, traffic_src = rec["bytes_per_launch"], "file: " + rec["source"]
         except (OSError, ValueError):
             pass
     if traffic is None:
-        msg = "NO PMC TRAFFIC RECORDED for workload %r in profiles/traffic.json (run tools/pmc_run.sh): roofline.traffic is null" % key
+        msg = "no PMC traffic for workload %r (live pass unavailable, none recorded in profiles/traffic.json): roofline.achieved / frac are null" % key
         log("!!! " + msg)
         traffic_src = "MISSING: " + msg
         if args.require_traffic:
             raise SystemExit(msg)
-    if rank == 0:
-        total_q = world * n_q * args.steps
-        avg_ms = float(np.mean(kernel_ms))
-        achieved = alg_timed / (avg_ms * 1e-3) / 1e9
-        metric_name = "fuzzy queries/sec (k=%d, %s≥%.2g) on %s-string dict" % (k, args.metric.capitalize(), args.similarity, _human(args.dict_size))
+    index.close()
+    if rank != 0:
+        return None
+    total_q = world * n_q * steps
+    avg_ms = float(np.mean(kernel_ms))
+    effective = alg_timed / (avg_ms * 1e-3) / 1e9
+    wire = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+    roof = {"bound": "hbm", "achieved": wire, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wire / HBM_PEAK_GBS if wire else None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": traffic / alg_timed if traffic else None,
+            "kernel": "sg_search_kernel_t", "kernel_ms_avg": avg_ms,
+            "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
+            "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
+            "note": "achieved/frac = measured HBM bytes per launch (PMC) / kernel time: the physical fraction of the 8 TB/s peak. "
+                    "effective_* = algorithmic (ScanCount-volume, SURVEY.md 8d) bytes / the same time: list skipping and the compressed "
+                    "posting store read less than that volume, so it may exceed the peak and is not a bandwidth. "
+                    "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
+                    "queries and the two query-ordering launches (~10 us) before them"}
+    rec = {
+        "value": total_q / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]%s), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU, %d distinct batches in rotation"
+                               % (_human(w["dict_size"]), "" if w["variant"] == "uniform" else ", variant " + w["variant"],
+                                  w["ngram"], w["metric"], w["similarity"], k, n_q, n_b),
+                   "baseline_config": w["name"],
+                   "parallelism": "query-sharded x%d, index replica per GPU, one process per GPU%s"
+                                  % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
+                   "rccl_gather_check": gather_ok,
+                   "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
+                             "build": args.build},
+                   "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt]))},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+    }
+    if host:
+        rec["host_buffers"] = {"value": host, "unit": "queries/s",
+                               "note": "sg_suggest_batch: pageable host buffers in and out over PCIe, synchronous (never `value`)"}
+    if replicas:
+        rec["replicas_mode"] = replicas
+    if parity:
+        rec["parity_vs_oracle"] = parity
+    return rec
+
+
+def replicas_measure(env, args, index, w, batches, ids0, cnt0, n_gpus, steps, warmup):
+    """ONE process, a replica per GPU behind one handle, the batch sliced over them by sg_suggest_batch_multi (host buffers in
+    and out, a worker thread per replica).  The step is n_gpus x the per-GPU batch; slice 0 of every step is this rank's batch
+    b, so its rows must equal the device-resident run's."""
+    import numpy as np
+    devices = [0] * n_gpus if env.single_device else list(range(n_gpus))
+    t0 = time.time()
+    index.replicate(devices)
+    env.log("[%s] %d replicas resident (%s) after %.1fs" % (w["name"], len(index.replicas()), index.replicas(), time.time() - t0))
+    k, n_q = w["topk"], w["queries"]
+    big = []
+    for b in range(len(batches)):      # n_gpus copies of batch b (same work per slice as the process-per-GPU run does per rank)
+        qb, qo = batches[b]
+        blob = np.concatenate([qb] * n_gpus)
+        offs = np.concatenate([[0]] + [qo[1:].astype(np.uint64) + np.uint64(i * int(qo[-1])) for i in range(n_gpus)]).astype(np.uint64)
+        big.append((blob, offs))
+    for i in range(warmup):
+        index.suggest_batch(blob=big[i % len(big)][0], offs=big[i % len(big)][1], metric=w["metric"], similarity=w["similarity"], k=k, multi=True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r_ids, r_sc, r_cnt = index.suggest_batch(blob=big[i % len(big)][0], offs=big[i % len(big)][1], metric=w["metric"],
+                                                 similarity=w["similarity"], k=k, multi=True)
+    dt = time.perf_counter() - t0
+    b_last = (steps - 1) % len(big)
+    ok = True
+    for g in range(n_gpus):
+        sl = slice(g * n_q, (g + 1) * n_q)
+        ok = ok and np.array_equal(r_cnt[sl], cnt0[b_last]) and np.array_equal(r_ids[sl], ids0[b_last])
+    if not ok:
+        raise RuntimeError("sg_suggest_batch_multi rows differ from the device-resident run's")
+    return {"value": steps * n_gpus * n_q / dt, "unit": "queries/s", "n_gpus": n_gpus, "devices": index.replicas(), "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "rows_equal_device_run": bool(ok),
+            "note": "ONE process: sg_index_replicate + sg_suggest_batch_multi, %d x %d queries per call from pageable host buffers, "
+                    "a worker thread per replica; PCIe-inclusive (never `value` of the process-per-GPU line)" % (n_gpus, n_q)}
+
+
+def workload_of(args, name):
+    w = dict(CONFIGS[name], name=name, variant=args.dict_variant if name == args.config else "uniform")
+    if name == args.config:
+        for kk in WORKLOAD_KEYS:
+            w[kk] = getattr(args, kk)
+    return w
+
+
+def main():
+    args = parse_args()
+    if args.config == "cfg5":
+        import bench_spell
+        return bench_spell.main(args)
+    apply_preset(args, args.config)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.mode == "procs" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)            # does not return
+    env = Env(args)
+    import numpy as np  # noqa: F401
+
+    w = workload_of(args, args.config)
+    if args.mode == "replicas":
+        return main_replicas(env, args, w)
+
+    subs = []
+    if args.sub_configs == "auto":
+        if env.world == 1 and args.config == "headline" and not args.explicit_workload and args.dict_variant == "uniform":
+            subs = ["cfg3", "cfg4", "cfg2"]
+    elif args.sub_configs != "none":
+        subs = [s for s in args.sub_configs.split(",") if s]
+        if env.world > 1:
+            raise SystemExit("--sub-configs is an N=1 option")
+    rec = measure(env, args, w, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline, traffic_mode=args.traffic,
+                  replicas_leg=env.world > 1)
+    sub_recs = {}
+    for name in subs:       # cfg3 and cfg4 first: they share the headline's dictionary
+        t0 = time.time()
+        sw = workload_of(args, name)
+        steps = max(5, min(args.steps, 10)) if name != "cfg4" else max(3, min(args.steps, 5))
+        r = measure(env, args, sw, steps, 2, cpu_baseline=False if args.no_cpu_baseline else 4.0, host_rate=False,
+                    traffic_mode=args.traffic)
+        if r:
+            roof = r["roofline"]
+            sub_recs[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "queries/s", "steps": r["steps"],
+                              "ms_per_step": r["ms_per_step"], "kernel_ms_avg": roof["kernel_ms_avg"],
+                              "frac": roof["frac"], "achieved_gbps": roof["achieved"], "traffic": roof["traffic"],
+                              "traffic_source": roof["traffic_source"],
+                              "effective_frac": roof["effective_frac"], "effective_gbps": roof["effective_gbps"],
+                              "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                              "bit_exact": (r.get("parity_vs_oracle") or {}).get("bit_exact"),
+                              "checked_queries": (r.get("parity_vs_oracle") or {}).get("checked_queries"),
+                              "cpu_baseline": r["cpu_baseline"], "results_per_query": r["config"]["results_per_query"]}
+            env.log("[%s] sub-record done in %.0fs" % (name, time.time() - t0))
+    if env.rank == 0:
+        k = w["topk"]
+        metric_name = "fuzzy queries/sec (k=%d, %s≥%.2g) on %s-string dict" % (k, w["metric"].capitalize(), w["similarity"], _human(w["dict_size"]))
         try:      # the headline workload carries BASELINE.json's metric string verbatim (its "HBM GB/s fraction" half is `roofline.frac`)
             base_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-            if base_metric.startswith(metric_name) and args.ngram == 3 and args.dict_variant == "uniform":
+            if base_metric.startswith(metric_name) and w["ngram"] == 3 and w["variant"] == "uniform":
                 metric_name = base_metric
         except (OSError, ValueError, KeyError):
             pass
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": "sg_search_kernel", "kernel_ms_avg": avg_ms,
-                "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
-                "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
-                "note": "achieved = algorithmic (ScanCount-volume) bytes / kernel time, SURVEY.md 8d; wire_* = PMC traffic / the same time; "
-                        "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
-                        "queries and the two query-ordering launches (~10 us) before them"}
-        if traffic:
-            roof["wire_gbps"] = traffic / (avg_ms * 1e-3) / 1e9
-            roof["wire_frac"] = roof["wire_gbps"] / HBM_PEAK_GBS
-            roof["traffic_over_algorithmic"] = traffic / alg_timed
-        out = {
-            "metric": metric_name,
-            "value": total_q / elapsed,
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 (posting/counter work) + f64 (final score)",
-            "data": "synthetic",
-            "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]%s), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU, %d distinct batches in rotation"
-                                   % (_human(args.dict_size), "" if args.dict_variant == "uniform" else ", variant " + args.dict_variant,
-                                      args.ngram, args.metric, args.similarity, k, n_q, n_b),
-                       "baseline_config": args.config,
-                       "parallelism": "query-sharded x%d, index replica per GPU%s" % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
-                       "rccl_gather_check": gather_ok,
-                       "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
-                                 "build": args.build},
-                       "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt]))},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-        }
-        if host_rate:
-            out["host_buffers"] = {"value": host_rate, "unit": "queries/s",
-                                   "note": "sg_suggest_batch: pageable host buffers in and out over PCIe, synchronous (never `value`)"}
-        if parity:
-            out["parity_vs_oracle"] = parity
+        out = {"metric": metric_name, "value": rec["value"], "unit": rec["unit"], "n_gpus": rec["n_gpus"], "steps": rec["steps"],
+               "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u32 (posting/counter work) + f64 (final score)", "data": "synthetic",
+               "config": rec["config"], "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"]}
+        for extra in ("host_buffers", "replicas_mode", "parity_vs_oracle"):
+            if extra in rec:
+                out[extra] = rec[extra]
+        if sub_recs:
+            out["configs"] = sub_recs
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if env.world > 1:
+        env.dist.destroy_process_group()
 
 
-def _live_traffic(args, log):
+def main_replicas(env, args, w):
+    """--mode replicas: the whole run is the single-process replica path; `value` is its (PCIe-inclusive) rate."""
+    import numpy as np
+    from suggest_amd import IndexDescription, NGramIndex, synth
+    n_gpus = args.gpus
+    have = env.torch.cuda.device_count()
+    if have < n_gpus and not env.single_device:
+        raise SystemExit("bench.py --mode replicas --gpus %d: only %d GPU(s) visible" % (n_gpus, have))
+    desc_kw = dict(synth.DESCRIPTION, ngram_size=w["ngram"])
+    k, n_q, n_b = w["topk"], w["queries"], max(1, args.batches)
+    blob, offs = get_dict(w["dict_size"], w["variant"])
+    batches = [synth.make_queries(n_q, blob, offs, seed=2, start=b * n_q) for b in range(n_b)]
+    index = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc_kw), device=0, build=args.build)
+    st = index.stats()
+    ref = [index.suggest_batch(blob=qb, offs=qo, metric=w["metric"], similarity=w["similarity"], k=k) for qb, qo in batches]
+    ids0 = [r[0] for r in ref]
+    cnt0 = [r[2] for r in ref]
+    rep = replicas_measure(env, args, index, w, batches, ids0, cnt0, n_gpus, args.steps, args.warmup)
+    out = {"metric": "fuzzy queries/sec (k=%d, %s≥%.2g) on %s-string dict; single-process replicas (sg_suggest_batch_multi), PCIe-inclusive"
+                     % (k, w["metric"].capitalize(), w["similarity"], _human(w["dict_size"])),
+           "value": rep["value"], "unit": "queries/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32 (posting/counter work) + f64 (final score)", "data": "synthetic",
+           "config": {"workload": "%s synthetic strings, q=%d, %s>=%.2g, k=%d, %d x %d-query host batch per call"
+                                  % (_human(w["dict_size"]), w["ngram"], w["metric"], w["similarity"], k, n_gpus, n_q),
+                      "baseline_config": w["name"], "parallelism": "ONE process, sg_index_replicate over %s, sg_suggest_batch_multi" % (rep["devices"],),
+                      "pcie_inclusive": True,
+                      "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"]}},
+           "roofline": None, "cpu_baseline": None, "replicas_mode": rep}
+    print(json.dumps(out), flush=True)
+
+
+def _live_traffic(args, w, log):
     """HBM bytes per launch of the search kernel, measured now: this script again, as a child under `rocprofv3 --pmc
     FETCH_SIZE --kernel-trace` (PMC counters cannot be read from inside a process), a few steps of the same workload.
     bytes = FETCH_SIZE [KB] x 1024 x 2 — the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).
@@ -337,12 +556,12 @@ def _live_traffic(args, log):
     if not rocprof:
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
-    steps, warm = 4, 2
+    steps, warm = (4, 2) if w["name"] != "cfg4" else (2, 1)
     cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
-           os.path.abspath(__file__), "--config", args.config, "--dict-size", str(args.dict_size), "--queries", str(args.queries),
-           "--ngram", str(args.ngram), "--metric", args.metric, "--similarity", repr(args.similarity), "--topk", str(args.topk),
-           "--batches", str(args.batches), "--dict-variant", args.dict_variant, "--build", args.build,
-           "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none"]
+           os.path.abspath(__file__), "--config", w["name"], "--dict-size", str(w["dict_size"]), "--queries", str(w["queries"]),
+           "--ngram", str(w["ngram"]), "--metric", w["metric"], "--similarity", repr(w["similarity"]), "--topk", str(w["topk"]),
+           "--batches", str(args.batches), "--dict-variant", w["variant"], "--build", args.build,
+           "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none", "--sub-configs", "none"]
     t0 = time.time()
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
@@ -360,7 +579,7 @@ def _live_traffic(args, log):
         if not main_k:
             return None, "no FETCH_SIZE rows for the search kernel in the child's counter CSV"
         kb = sum(main_k) / len(main_k) + (sum(parts_k) / len(main_k) if parts_k else 0.0)
-        log("live PMC pass: FETCH_SIZE %.6g KB per launch over %d launches (%.0fs)" % (kb, len(main_k), time.time() - t0))
+        log("[%s] live PMC pass: FETCH_SIZE %.6g KB per launch over %d launches (%.0fs)" % (w["name"], kb, len(main_k), time.time() - t0))
         return kb * 1024 * 2, ("live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass of this run, %d launches of this workload "
                                "(search + parts kernels): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (len(main_k), kb))
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:

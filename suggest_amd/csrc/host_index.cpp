@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <numeric>
+#include <exception>
 #include <thread>
 
 #include "sg_internal.h"
@@ -278,13 +279,25 @@ void build_term_table(HostIndex& ix) {
   }
 }
 
-// Runs fn(block) for block = 0 .. n-1 on n threads (block 0 on the caller's).
+// Runs fn(block) for block = 0 .. n-1 on n threads (block 0 on the caller's).  An exception in any block (bad_alloc at
+// 10M docs x 32 threads is the plausible one) is carried to the caller once every thread has been joined: nothing
+// escapes a worker (std::terminate) and no joinable thread is destroyed, so the C ABI still answers SG_E_NOMEM.
 template <class F>
 static void run_blocks(uint32_t n, F fn) {
+  std::vector<std::exception_ptr> failed(n);
+  auto guarded = [&fn, &failed](uint32_t b) {
+    try { fn(b); } catch (...) { failed[b] = std::current_exception(); }
+  };
   std::vector<std::thread> th;
-  for (uint32_t b = 1; b < n; b++) th.emplace_back([&fn, b] { fn(b); });
-  fn(0);
+  try {
+    for (uint32_t b = 1; b < n; b++) th.emplace_back(guarded, b);
+  } catch (...) {                                    // thread creation failed: the blocks without a thread run here
+    const uint32_t started = (uint32_t)th.size() + 1;
+    for (uint32_t b = started; b < n; b++) guarded(b);
+  }
+  guarded(0);
   for (auto& t : th) t.join();
+  for (auto& e : failed) if (e) std::rethrow_exception(e);
 }
 
 // What one thread learns about its contiguous block of docs in pass 1.

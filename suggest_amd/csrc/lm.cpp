@@ -138,7 +138,12 @@ static bool read_cdb_words(const char* path, std::vector<std::string>& words, st
   auto u32 = [&](size_t o) { return (uint32_t)(uint8_t)d[o] | ((uint32_t)(uint8_t)d[o + 1] << 8) | ((uint32_t)(uint8_t)d[o + 2] << 16) | ((uint32_t)(uint8_t)d[o + 3] << 24); };
   if (d.size() < 2048) { err = "cdb dictionary is truncated"; return false; }
   size_t end = d.size();
-  for (int i = 0; i < 256; i++) if (u32((size_t)i * 8 + 4)) end = std::min<size_t>(end, u32((size_t)i * 8));   // (an empty table has no position)
+  for (int i = 0; i < 256; i++) {
+    if (!u32((size_t)i * 8 + 4)) continue;                   // (an empty table has no position)
+    const size_t tpos = u32((size_t)i * 8);
+    if (tpos < 2048 || tpos > d.size()) { err = "cdb dictionary is corrupted: hash table inside the header or past the end"; return false; }
+    end = std::min<size_t>(end, tpos);
+  }
   std::map<uint32_t, std::string> by_id;
   for (size_t pos = 2048; pos + 8 <= end;) {
     const size_t klen = u32(pos), dlen = u32(pos + 4);
@@ -157,7 +162,8 @@ static bool read_cdb_words(const char* path, std::vector<std::string>& words, st
 // words in id order and lookups are exact.
 int lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_symbol, const char* end_symbol,
                    const std::vector<std::string>& alphabet, HostLM& lm, std::string& err) {
-  if (!read_cdb_words(cdb_path, lm.words, err)) return SG_E_INVALID;
+  lm.words.clear(); lm.id_of.clear(); lm.level.clear();
+  if (!read_cdb_words(cdb_path, lm.words, err)) { lm.words.clear(); return SG_E_INVALID; }
   for (uint32_t i = 0; i < lm.words.size(); i++) lm.id_of.emplace(lm.words[i], i);
   std::ifstream f(lm_path, std::ios::binary);
   if (!f) { err = std::string("failed to open the lm binary file: ") + lm_path; return SG_E_INVALID; }
@@ -182,11 +188,14 @@ int lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_
     std::vector<uint32_t> start((size_t)n_parents + 2, 0xFFFFFFFFu);
     start[(size_t)n_parents + 1] = (uint32_t)n_v;
     uint64_t prev = 0;
+    uint32_t prev_from = 0;
     for (size_t i = 0; i < n_c; i++) {
       const uint64_t c = u64(pos + i * 8);
       const uint32_t ctx = (uint32_t)(c >> 32), from = (uint32_t)c;
-      if ((i && c <= prev) || from > n_v) { err = "packed array containers are not ascending"; return SG_E_INVALID; }
-      prev = c;
+      // contexts ascend AND so do their offsets: a bucket is [from, next from) — an offset that steps back would give a
+      // bucket with from > to, and the searches (host lower_bound, device binary / 64-ary search) would leave the array
+      if ((i && c <= prev) || from > n_v || from < prev_from) { err = "packed array containers are not ascending"; return SG_E_INVALID; }
+      prev = c; prev_from = from;
       const uint32_t bucket = ctx == kNoContext ? n_parents : ctx;
       if (bucket > n_parents) { err = "packed array context outside the previous level"; return SG_E_INVALID; }
       start[bucket] = from;
@@ -195,7 +204,15 @@ int lm_load_binary(const char* lm_path, const char* cdb_path, const char* start_
     lv.child_begin = std::move(start);
     pos += (size_t)cs;
     lv.word.resize(n_v); lv.count.resize(n_v);
-    for (size_t i = 0; i < n_v; i++) { const uint64_t v = u64(pos + i * 8); lv.word[i] = (uint32_t)(v >> 32); lv.count[i] = (uint32_t)v; }
+    for (size_t i = 0; i < n_v; i++) {
+      const uint64_t v = u64(pos + i * 8);
+      lv.word[i] = (uint32_t)(v >> 32); lv.count[i] = (uint32_t)v;
+      if (lv.word[i] >= lm.words.size() && lv.word[i] != kUnknownWord) { err = "packed array holds a word id outside the dictionary"; return SG_E_INVALID; }
+    }
+    for (size_t b = 0; b + 1 < lv.child_begin.size(); b++)       // a bucket is searched by word: strictly ascending inside
+      for (uint32_t i = lv.child_begin[b] + 1; i < lv.child_begin[b + 1]; i++)
+        if (lv.word[i] <= lv.word[i - 1]) { err = "packed array values of a context are not ascending by word"; return SG_E_INVALID; }
+    if (total > 0xFFFFFFFFull) { err = "packed array total does not fit 32 bits"; return SG_E_INVALID; }
     pos += (size_t)vs;
     lm.level.push_back(std::move(lv));
   }

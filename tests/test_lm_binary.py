@@ -97,6 +97,65 @@ def test_binary_loader_rejects_bad_files(tmp_path):
         LanguageModel(binary=os.path.join(LM_DIR, "test.lm"), dictionary=str(tmp_path / "nope.cdb"))
 
 
+def _rewrite_level(data, level, fn):
+    """the bytes of a .lm file with fn(containers, values) -> (containers, values) applied to one level"""
+    order, pos, out = data[5], 6, bytearray(data[:6])
+    for lv in range(order):
+        nl = data.index(b"\n", pos)
+        cs, vs, total = (int(x) for x in data[pos:nl].split())
+        pos = nl + 1
+        c = np.frombuffer(data[pos:pos + cs], dtype="<u8").copy(); pos += cs
+        v = np.frombuffer(data[pos:pos + vs], dtype="<u8").copy(); pos += vs
+        if lv == level:
+            c, v = fn(c, v)
+        out += b"%d %d %d\n" % (c.size * 8, v.size * 8, total) + c.astype("<u8").tobytes() + v.astype("<u8").tobytes()
+    return bytes(out) + data[pos:]
+
+
+def test_binary_loader_rejects_models_whose_searches_would_leave_the_arrays(tmp_path):
+    """A malformed / corrupted .lm (round-2 advisor): container offsets that step back give a bucket with from > to — the host
+    lower_bound and the device's binary / 64-ary searches would read outside the arrays; word ids outside the dictionary;
+    buckets that are not sorted by word; a cdb whose hash tables lie inside its header."""
+    from suggest_amd import _lib
+    from suggest_amd.spell import LanguageModel
+    good = open(os.path.join(LM_DIR, "test.lm"), "rb").read()
+    cdb = os.path.join(LM_DIR, "test.cdb")
+
+    def load(name, data, dictionary=cdb):
+        (tmp_path / name).write_bytes(data)
+        return LanguageModel(binary=str(tmp_path / name), dictionary=dictionary)
+
+    load("same.lm", _rewrite_level(good, 1, lambda c, v: (c, v)))                       # the rewrite itself is faithful
+
+    def from_steps_back(c, v):
+        assert c.size >= 3
+        c[2] = (c[2] & np.uint64(0xFFFFFFFF00000000)) | ((c[1] & np.uint64(0xFFFFFFFF)) - np.uint64(1))   # contexts still ascend
+        return c, v
+    with pytest.raises(_lib.SuggestHipError, match="not ascending"):
+        load("back.lm", _rewrite_level(good, 1, from_steps_back))
+
+    def foreign_word(c, v):
+        v[0] = (np.uint64(0x00FFFFF0) << np.uint64(32)) | (v[0] & np.uint64(0xFFFFFFFF))
+        return c, v
+    with pytest.raises(_lib.SuggestHipError, match="outside the dictionary"):
+        load("word.lm", _rewrite_level(good, 0, foreign_word))
+
+    def unsorted_bucket(c, v):
+        v[[0, 1]] = v[[1, 0]]
+        return c, v
+    with pytest.raises(_lib.SuggestHipError, match="not ascending by word"):
+        load("unsorted.lm", _rewrite_level(good, 0, unsorted_bucket))
+
+    raw = bytearray(open(cdb, "rb").read())
+    for i in range(256):                                                                  # first non-empty table -> byte 100
+        if struct.unpack_from("<I", raw, i * 8 + 4)[0]:
+            struct.pack_into("<I", raw, i * 8, 100)
+            break
+    (tmp_path / "bad.cdb").write_bytes(bytes(raw))
+    with pytest.raises(_lib.SuggestHipError, match="corrupted"):
+        load("ok.lm", good, dictionary=str(tmp_path / "bad.cdb"))
+
+
 # ---- SpellChecker.Predict: vectors derived BY HAND from pkg/spellchecker/spellchecker.go:40-92 on the fixture model ----
 # (the reference has no test for Predict; these pin the oracle — and, on the GPU box, the product — independently of each other)
 # ids (count desc, word asc): 0 </S>  1 <S>  2 i  3 am  4 sam  5 and  6 do  7 eggs  8 green  9 ham  10 like  11 not
