@@ -26,6 +26,8 @@
 #include <thread>
 #include <functional>
 #include <string>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "sg_internal.h"
 
@@ -38,6 +40,8 @@ namespace sg {
 #define SG_DUP_SCRATCH (2 * SG_MAX_A + 64 + 64)   // LDS words of the repeated-term (secondary entry) path (borrowed from the row table)
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
+#define SG_PPC 7           // postings per 16-byte chunk of the packed store: {u32 first x, 6 x u16 gaps} (packed_store.inc)
+#define SG_SUB 2           // rows counted per LDS round trip: SG_SUB * SG_PPC = 14 atomics issued, one wait
 #define SG_EPOCHS 4           // group passes whose candidates may wait in the queue together (ring of their streamed-list masks + docID ranges)
 #define SG_EPOCH_WORDS 6
 // LDS layout of a search wavefront.  Two sets of table sizes: the full one, and a slim one that — with 2^11 counter words,
@@ -74,9 +78,14 @@ inline uint32_t sg_queue_cap(uint32_t log2_cnt, uint32_t k, bool roomy, bool sli
 #define SG_MAX_PARTS 32       // parts a heavy query is cut into
 
 struct DeviceIndex {
+  // The packed posting store (packed_store.inc): documents are numbered x = seg_base[cardinality] + rank inside the segment
+  // (ascending docID), a 16-byte chunk holds SG_PPC postings as {u32 first x, 6 x u16 gaps}.  Everything below the top-k
+  // works in x; orig_of[] maps back where a document is offered to the top-k (whose order is by ORIGINAL docID).
   const uint32_t* postings;
-  const uint32_t* cut_sample;  // [ceil(n_chunks/16)+1] docID of the first posting of every 16th chunk of the posting store
-  const uint32_t* seg_off;
+  const uint32_t* cut_sample;  // [ceil(n_chunks/16)+1] x of the first posting of every 16th chunk of the posting store
+  const uint32_t* seg_off;     // [n_terms * (S+1)] first chunk of list (term, segment), term-major
+  const uint32_t* orig_of;     // [n_docs] x -> docID
+  const uint32_t* seg_base;    // [S+1] first x of every cardinality segment
   const TermSlot* slots;
   const uint8_t* ascii_sym;    // [128]
   const uint8_t* ascii_alpha;  // [128]
@@ -96,7 +105,7 @@ struct DeviceIndex {
   const uint32_t* list_len;    // [n_terms*S] stored (de-duplicated) list lengths
   // forward index (doc -> its distinct terms), derived from the CSR on the device (forward_index.inc): verifying a
   // candidate is ONE coalesced read of its term list instead of a binary search in every query term's posting list
-  const uint2* fwd_rec;        // [n_docs] {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
+  const uint2* fwd_rec;        // [n_docs] indexed by x: {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
   const uint32_t* fwd_terms;   // term ids, a doc's list padded to a whole chunk with 0xFFFFFFFF
   uint32_t n_dups, n_dup_docs, n_extra;
   uint32_t slot_mask, n_na, n_lower;
@@ -139,6 +148,7 @@ struct BatchArgs {
   // a launch over a subset of the batch (the spellchecker's fuzzy top-up): workgroup b runs query q_sel[b], b < *q_sel_n
   const uint32_t* q_sel;
   const uint32_t* q_sel_n;
+  uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative, one query in 32
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
@@ -682,14 +692,24 @@ __device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T, uin
 }
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8v __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-static_assert(SG_UNROLL == 4, "u32x16 below holds 4 rows x 4 postings");
+static_assert(SG_UNROLL == 4 && SG_SUB == 2 && SG_SUB * SG_PPC <= 16, "u32x16 below holds SG_SUB rows x SG_PPC postings");
 
-// Counts one batch of SG_UNROLL rows (a row = up to 64 consecutive 16-byte chunks of ONE posting
-// list, one chunk per lane): one LDS atomic per posting (U8: four u8 counters per word, else one
-// u32 counter per word), issued back to back and waited for once.  live[u] is 1 for lanes inside
-// the list, 0 for lanes past its end (they re-read the list's last chunk and add 0).  Returns the
-// ballot of lanes holding a posting whose bucket reached T; `was` receives the counts seen.
+// The SG_PPC postings of one packed chunk: first x, then six 16-bit gaps (a gap of 0 repeats the previous posting: padding).
+template <class V>
+__device__ __forceinline__ void decode_chunk(const uint4& v, V& p, int at) {
+  p[at] = v.x;
+  p[at + 1] = p[at] + (v.y & 0xFFFFu); p[at + 2] = p[at + 1] + (v.y >> 16);
+  p[at + 3] = p[at + 2] + (v.z & 0xFFFFu); p[at + 4] = p[at + 3] + (v.z >> 16);
+  p[at + 5] = p[at + 4] + (v.w & 0xFFFFu); p[at + 6] = p[at + 5] + (v.w >> 16);
+}
+
+// Counts SG_SUB rows (a row = up to 64 consecutive 16-byte chunks of ONE posting list, one chunk = SG_PPC postings per
+// lane): one LDS atomic per posting (U8: four u8 counters per word, else one u32 counter per word), issued back to back
+// and waited for once.  live[u] is 1 for lanes inside the list, 0 for lanes past its end (they re-read the list's last
+// chunk and add 0).  Returns the ballot of lanes holding a posting whose bucket reached T; `pp` receives the decoded
+// postings, `was` the counts seen.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // LDS byte address of the counter word of doc d.  amask selects the bucket bits of the docID and is
@@ -701,44 +721,48 @@ __device__ __forceinline__ lds_u32* counter_word(uint32_t d, uint32_t amask, uin
 }
 
 template <bool U8>
-__device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], uint32_t amask,
-                                               uint32_t cbase, uint32_t dummy, uint32_t Tm1, u32x16& was) {
-  uint32_t old[4 * SG_UNROLL];
-  uint32_t shf[U8 ? 4 * SG_UNROLL : 1];
+__device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_SUB], const uint32_t (&live)[SG_SUB], uint32_t amask,
+                                               uint32_t cbase, uint32_t dummy, uint32_t Tm1, u32x16& pp, u32x16& was, uint32_t& mx) {
+  uint32_t old[SG_SUB * SG_PPC];
 #pragma unroll
-  for (int u = 0; u < SG_UNROLL; u++) {
-    const uint32_t dv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+  for (int u = 0; u < SG_SUB; u++) {
+    // the six gaps; a zero gap repeats the previous posting (the padding of a list's last chunk, or of a chunk cut short by a
+    // gap above 65 535): it adds NOTHING — counted, the copies would pre-load a bucket at every list end with up to six
+    // phantom postings and flag whatever else falls into it (measured: 3x the flagged postings at thresholds of 6..11)
+    const uint32_t g[SG_PPC] = {1u, v[u].y & 0xFFFFu, v[u].y >> 16, v[u].z & 0xFFFFu, v[u].z >> 16, v[u].w & 0xFFFFu, v[u].w >> 16};
     // Lanes past the end of the list hold copies of its last chunk; aimed at the real counters they would
-    // all hit the same four words (address conflicts serialise LDS atomics).  They add 0 to a lane-private
+    // all hit the same words (address conflicts serialise LDS atomics).  They add 0 to a lane-private
     // dummy word instead: per ROW two selects, per posting still one v_and_or_b32.
     const uint32_t am = live[u] ? amask : 0u;
     const uint32_t cb = live[u] ? cbase : dummy;
+    uint32_t d = v[u].x;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      lds_u32* w = counter_word(dv[e], am, cb);
+    for (int e = 0; e < SG_PPC; e++) {
+      if (e) d += g[e];
+      pp[u * SG_PPC + e] = d;
+      const uint32_t inc = min(g[e], live[u]);                 // 1 for a posting of a live lane, else 0
+      lds_u32* w = counter_word(d, am, cb);
       if (U8) {
         // byte lane = docID & 3: the shift amount is (d << 3) mod 32 — the hardware shifters and v_bfe use
-        // only the low 5 bits, so no masking instruction is needed (dead lanes add into their dummy word)
-        const uint32_t sh = dv[e] << 3;
-        shf[u * 4 + e] = sh;
-        old[u * 4 + e] = __hip_atomic_fetch_add(w, 1u << (sh & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // only the low 5 bits, so no masking instruction is needed
+        old[u * SG_PPC + e] = __hip_atomic_fetch_add(w, inc << ((d << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
-        old[u * 4 + e] = __hip_atomic_fetch_add(w, live[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old[u * SG_PPC + e] = __hip_atomic_fetch_add(w, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
-  // one wait for all sixteen returns (left alone the compiler may stage it: lgkmcnt(11), (10), (8) ... — fifteen more
+  // one wait for all the returns (left alone the compiler may stage it: lgkmcnt(11), (10), (8) ... — a dozen more
   // instructions in a loop that is issue-bound)
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
-  uint32_t mx = 0;
+  mx = 0;
 #pragma unroll
-  for (int u = 0; u < SG_UNROLL; u++) {
+  for (int u = 0; u < SG_SUB; u++) {
     uint32_t mu = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      uint32_t o = old[u * 4 + e];
-      if (U8) o = __builtin_amdgcn_ubfe(o, shf[u * 4 + e], 8u);   // v_bfe_u32 reads offset[4:0] only
-      was[u * 4 + e] = o;
+    for (int e = 0; e < SG_PPC; e++) {
+      uint32_t o = old[u * SG_PPC + e];
+      if (U8) o = __builtin_amdgcn_ubfe(o, pp[u * SG_PPC + e] << 3, 8u);   // v_bfe_u32 reads offset[4:0] only
+      was[u * SG_PPC + e] = o;
       mu = max(mu, o);
     }
     mx = max(mx, live[u] ? mu : 0u);
@@ -999,15 +1023,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t epoch = 0, flushed_at = 0;                         // running group number; its value at the last flush
     uint64_t str_m[2] = {0, 0};                                 // query positions whose list the current group streams
     uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;                  // docID range of the current pass (whole range outside pass groups)
+    // (d = the ORIGINAL docID: the top-k's order, the LM's word ids and the results are in the caller's numbering)
     auto offer = [&](uint32_t d, int overlap, int w) {
       if (kLM)                                                              // lmCollector: score = ScoreNext(doc), monotone in the count
         topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
-      else if (a.autocomplete) topk_insert(tk, ~(uint64_t)d, d, lane);     // score = -docID, collector.go:104-106
+      else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }   // score = -docID, collector.go:104-106
       else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
     };
     // which query-term occurrences hold doc d in segment w, by binary search in their lists: only documents that repeat a
     // term come here (the secondary entries of SURVEY.md §A.3 need the per-list view)
-    auto exact_masks = [&](uint32_t d, int w, uint64_t (&fm)[2]) -> int {
+    auto exact_masks = [&](uint32_t x, int w, uint64_t (&fm)[2]) -> int {
       fm[0] = fm[1] = 0;
       int c = 0;
       for (int r = 0; r < a_rounds; r++) {
@@ -1015,11 +1040,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         bool found = false;
         if (i < A) {
           const uint32_t s0 = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0;
-          if (nch) {
+          if (nch) {                                             // the last chunk that begins at or before x, then its postings
             const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
-            uint32_t lo = 0, hi = nch * 4;
-            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (p[mid] < d) lo = mid + 1; else hi = mid; }
-            found = lo < nch * 4 && p[lo] == d;
+            uint32_t lo = 0, hi = nch;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[(uint64_t)mid * 4] <= x) lo = mid + 1; else hi = mid; }
+            if (lo) {
+              u32x8v pc;
+              decode_chunk(post4[s0 + lo - 1u], pc, 0);
+#pragma unroll
+              for (int e = 0; e < SG_PPC; e++) found |= pc[e] == x;
+            }
           }
         }
         const uint64_t m = ballot(found);
@@ -1028,7 +1058,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       return c;
     };
-    auto emit = [&](uint32_t d, int overlap, int w) {
+    auto emit = [&](uint32_t x, uint32_t d, int overlap, int w) {   // x: the store's number of the document, d: its docID
       const int T = (int)readlane((uint32_t)seg_T, w);
       if (DBG_SKIP(2048u)) { topk_insert(tk, score_bits((double)overlap + (double)T / 1000.0 + (double)w / 1e6), d, lane); return; }
       if (overlap < T) return;
@@ -1038,7 +1068,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u) {
           uint64_t fm[2];
           __syncthreads();
-          exact_masks(d, w, fm);
+          exact_masks(x, w, fm);
           // (which secondary entries CPMerge produces depends on the threshold it ran with: the metric's own, not the tightened one)
           const int T0 = a.autocomplete ? A : d_threshold(a.metric, a.alpha, A, tb + w);
           const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T0, d, fm[0], fm[1], lane);
@@ -1092,7 +1122,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         my_jj = (uint32_t)lane < n ? qj[lane] : 0u;
       }
       uint2 rec = make_uint2(0u, 0u);
-      if ((uint32_t)lane < n) rec = ix.fwd_rec[my_doc];
+      uint32_t my_orig = 0u;                                    // (one load per candidate, side by side: the serial emit loop has it at hand)
+      if ((uint32_t)lane < n) { rec = ix.fwd_rec[my_doc]; my_orig = ix.orig_of[my_doc]; }
       uint32_t nd_max = rec.y >> 16;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) nd_max = max(nd_max, (uint32_t)__shfl_xor((int)nd_max, off, 64));
@@ -1164,7 +1195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (!(v >> 31)) continue;
         DBG_COUNT(6, 1)
         const uint32_t card = readlane(rec.y, (int)c) & 0xFFFFu;
-        emit(qd[c], (int)(v & 0xFFu), (int)card - tb);
+        emit(qd[c], readlane(my_orig, (int)c), (int)(v & 0xFFu), (int)card - tb);
       }
       __syncthreads();
       }
@@ -1178,7 +1209,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (seg_valid) {
       const int k = (seg_T > a.t_floor && !DBG_SKIP(8u)) ? min(seg_T - a.t_floor, A - 1) : 0;
       const uint32_t rem = seg_tot - (uint32_t)((float)seg_tot * (float)k * (1.0f / (float)A));
-      seg_need = max(1u, buckets_needed(rem * 4u, seg_T - k, a.filter_level));
+      seg_need = max(1u, buckets_needed(rem * SG_PPC, seg_T - k, a.filter_level));
     }
 
     // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
@@ -1247,7 +1278,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
           const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
           const int k_skip = (int)(popc64(pick0) + popc64(pick1));
-          if (buckets_needed((L - skipped) * 4u, Tmin - k_skip, a.filter_level) <= max_buckets) {
+          if (buckets_needed((L - skipped) * SG_PPC, Tmin - k_skip, a.filter_level) <= max_buckets) {
             skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
           }
         }
@@ -1255,7 +1286,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = buckets_needed(Leff * 4u, Teff, a.filter_level);
+      const uint32_t need = buckets_needed(Leff * SG_PPC, Teff, a.filter_level);
       bool u8 = need > cnt_words && Teff <= 200;
       uint32_t lg = 8;
       {
@@ -1271,34 +1302,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       uint32_t ep_tag = 0, q0 = qn;                             // (set at the top of every pass)
       // slow path of one counted batch whose row descriptors are rows4[0..3]: the flagged postings go to the queue
       // (per posting slot one ballot + a prefix count: the lanes store their own postings)
-      auto flagged = [&](const uint4 (&v)[SG_UNROLL], const uint32_t (&live)[SG_UNROLL], const u32x16& was,
-                         uint32_t row0, uint32_t Tm1) {
-        const u32x16 vv = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
-                           v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
-        uint32_t fl = 0;
-#pragma unroll
-        for (int ue = 0; ue < 4 * SG_UNROLL; ue++)       // (a list's last chunk is padded with copies of its last docID: one posting, not four)
-          fl |= ((live[ue >> 2] && was[ue] >= Tm1 && !((ue & 3) && vv[ue] == vv[ue - 1])) ? 1u : 0u) << ue;
-        if (u8) {
-          // a u8 counter about to wrap would carry into its neighbour and — worse — undercount its own bucket.  Every
-          // increment returns the value it found, and a counter passes through every value on its way up, so "some
-          // posting found >= 250" is seen before any wrap (reading the counter afterwards is not: identical lists of a
-          // query that repeats a term can push one bucket past 255 within a single batch).
-          uint32_t hot = 0;
-#pragma unroll
-          for (int ue = 0; ue < 4 * SG_UNROLL; ue++) hot |= (live[ue >> 2] && was[ue] >= 250u) ? 1u : 0u;
-          if (ballot(hot != 0)) saturated = true;
-        }
+      auto flagged = [&](const u32x16& vv, const uint32_t (&live)[SG_SUB], const u32x16& was, uint32_t mx, uint32_t row0, uint32_t Tm1) {
+        // a u8 counter about to wrap would carry into its neighbour and — worse — undercount its own bucket.  Every
+        // increment returns the value it found, and a counter passes through every value on its way up, so "some
+        // posting found >= 250" is seen before any wrap (reading the counter afterwards is not: identical lists of a
+        // query that repeats a term can push one bucket past 255 within a single batch).
+        if (u8 && ballot(mx >= 250u)) saturated = true;
         if (overflow) return;                                    // (the saturation watch above goes on)
-        uint32_t any_fl = fl;                                    // OR over the wave: the posting slots flagged in any lane
+        // the posting slots flagged in any lane: one compare per slot, its lane mask IS the ballot (no per-lane bit
+        // fields, no reduction over the wave); which lanes, and whether they hold a real posting, is settled per slot below
+        uint32_t any_fl = 0;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) any_fl |= (uint32_t)__shfl_xor((int)any_fl, off, 64);
-        any_fl = __builtin_amdgcn_readfirstlane(any_fl);
+        for (int ue = 0; ue < SG_SUB * SG_PPC; ue++) any_fl |= (ballot(live[ue / SG_PPC] && was[ue] >= Tm1) ? 1u : 0u) << ue;
         while (any_fl) {                                         // (vv[ue]: a uniform dynamic index into the register vector)
           const int ue = __builtin_ctz(any_fl);
           any_fl &= any_fl - 1u;
-          const bool mine = (fl >> ue) & 1u;
+          const int e = ue >= SG_PPC ? ue - SG_PPC : ue;
+          // (zero gaps repeat a posting — the padding of a chunk: one posting, not several)
+          const bool mine = (ue >= SG_PPC ? live[1] : live[0]) && was[ue] >= Tm1 && !(e && vv[ue] == vv[ue ? ue - 1 : 0]);
           const uint64_t m = ballot(mine);
+          if (!m) continue;
           const uint32_t cnt_f = popc64(m);
           DBG_COUNT(2, cnt_f)
           // a full queue is not emptied here (verification in the middle of the stream loop costs the loop its registers):
@@ -1306,7 +1329,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           if (qn + cnt_f > cq_cap || DBG_SKIP(1024u)) { overflow = true; break; }
           DBG_COUNT(3, cnt_f)
           const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = (uint32_t)rowlist[row0 + (uint32_t)(ue >> 2)] | ep_tag; }
+          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = (uint32_t)rowlist[row0 + (uint32_t)(ue >= SG_PPC ? 1 : 0)] | ep_tag; }
           qn += cnt_f;
         }
       };
@@ -1319,37 +1342,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       uint32_t n_pass = 1;
       if (g0 == g1 && need > max_buckets) n_pass = min(1024u, (need + max_buckets - 1u) / max_buckets);   // (as many as needed: a power of two wasted up to half)
       const uint32_t full_ls[2] = {ls_r[0], ls_r[1]}, full_ln[2] = {ln_r[0], ln_r[1]};
-      uint32_t prev_lo[2] = {0, 0};                             // per list: a posting index <= the first posting of the range
+      uint32_t prev_lo[2] = {0, 0};                             // per list: a chunk that begins below the range (or the list's first)
       uint32_t g_cur[2] = {(full_ls[0] + 15u) >> 4, (full_ls[1] + 15u) >> 4};   // per list: cursor into cut_sample
+      // (a single segment: its documents are the numbers seg_base[B] .. seg_base[B + 1], and the passes divide THAT range)
+      const uint32_t pass_x0 = n_pass > 1 ? ix.seg_base[tb + g0] : 0u, pass_span = n_pass > 1 ? ix.seg_base[tb + g0 + 1] - pass_x0 : 0u;
       for (uint32_t pass = 0; pass < n_pass; pass++) {
       DBG_COUNT(4, 1)
       if (n_pass > 1) {
-        lo_doc = (uint32_t)(((uint64_t)ix.n_docs * pass) / n_pass);
-        hi_doc = pass + 1 == n_pass ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)ix.n_docs * (pass + 1)) / n_pass);
-        // Cut every list at hi_doc.  The cut need not be exact: any [lo, hi] around the true lower bound will do
-        // (the pass ends at hi, the next one starts at lo; a few postings counted twice only loosen the filter).
-        // Binary-searching the lists themselves costs ~17 random 128 B lines per list and pass — as much HBM
-        // traffic as the postings the pass streams (PMC: TCC_EA0_RDREQ 1.65x the algorithmic volume).  Instead a
-        // cursor per list advances over cut_sample (contiguous, one u32 per 64 postings, 1.6 % of the store) to
-        // the 16-chunk block that straddles hi_doc: no probe of the list, <= 64 postings of slack per cut.
+        lo_doc = pass_x0 + (uint32_t)(((uint64_t)pass_span * pass) / n_pass);
+        hi_doc = pass + 1 == n_pass ? 0xFFFFFFFFu : pass_x0 + (uint32_t)(((uint64_t)pass_span * (pass + 1)) / n_pass);
+        // Cut every list at hi_doc, in whole chunks: [prev_lo, hi) is streamed, where chunk hi begins at or above hi_doc
+        // (everything in it belongs to later passes) and the next pass starts at lo, a chunk that begins below hi_doc — all
+        // chunks before it lie wholly below (a chunk ends where the next begins).  The cut need not be tight: a few
+        // postings counted in two passes only loosen the filter, and a candidate is emitted in the pass that owns its number.
+        // Binary-searching the lists themselves costs ~17 random 128 B lines per list and pass — as much HBM traffic as
+        // the postings the pass streams.  Instead a cursor per list advances over cut_sample (contiguous, one u32 per 16
+        // chunks, under 1 % of the store) to the 16-chunk block that straddles hi_doc, and one round of probes inside it.
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-          const uint32_t n = full_ln[r] * 4;
+          const uint32_t n = full_ln[r];                        // chunks
           uint32_t lo = prev_lo[r], hi = n;
           if (pass + 1 != n_pass && r < a_rounds) {
             const uint32_t s0 = full_ls[r], g_first = (s0 + 15u) >> 4, g_end = (s0 + full_ln[r] + 15u) >> 4;
             // bracket [glo, ghi]: every sample before glo is < hi_doc, sample ghi is >= hi_doc (or ghi == g_end).
             // 8 independent loads per round: around the position the remaining samples predict when the cursor
-            // has far to go (docIDs of a list are close to uniform), then 9-ary, then 8 consecutive samples.
+            // has far to go (the numbers of a list are close to uniform over the segment's range), then 9-ary, then 8
+            // consecutive samples.
             uint32_t glo = g_cur[r], ghi = g_end;
             const uint32_t step = (g_end - glo) / (n_pass - pass);
             bool predict = true;
             while (ballot(glo < ghi)) {
               uint32_t pos[8], sv[8];
               const uint32_t span = ghi - glo;
-              // (the docIDs of a list are uniform: where the boundary falls in a list of n postings has a standard deviation
-              //  of sqrt(p(1-p)n) postings — under one sample of 64 for n < 10^4 — so eight CONSECUTIVE samples around the
-              //  prediction bracket it in one round trip almost always; a miss falls through to the 9-ary rounds)
+              // (where the boundary falls in a list of n postings has a standard deviation of sqrt(p(1-p)n) postings — about a
+              //  sample for n < 10^4 — so eight CONSECUTIVE samples around the prediction bracket it in one round trip
+              //  almost always; a miss falls through to the 9-ary rounds)
               const uint32_t base = glo + step > 3u ? glo + step - 3u : 0u;
 #pragma unroll
               for (int i = 0; i < 8; i++) {
@@ -1367,28 +1394,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
             const uint32_t g = ghi;
             g_cur[r] = g;
-            lo = max(lo, g > g_first ? ((((g - 1u) << 4) - s0) << 2) : 0u);
-            hi = min(n, g < g_end ? (((g << 4) - s0) << 2) : n);
+            lo = max(lo, g > g_first ? ((g - 1u) << 4) - s0 : 0u);      // sample g - 1 (chunk 16 (g - 1)) begins below hi_doc
+            hi = min(n, g < g_end ? (g << 4) - s0 : n);                 // sample g begins at or above it
             lo = min(lo, hi);
-            // one round of probes inside the straddling block (two 128 B lines this pass and the next stream anyway):
-            // short lists get cuts to within two chunks — with many passes a 64-posting slack would re-read them whole
+            // one round of probes on the first postings of the chunks in between (two 128 B lines this pass and the next
+            // stream anyway): cuts to within two chunks — with many passes a 16-chunk slack would re-read short lists whole
             const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
-            while (ballot(hi - lo > 8u)) {
+            while (ballot(hi - lo > 2u)) {
               uint32_t pos[8], val[8];
 #pragma unroll
               for (int i = 0; i < 8; i++) {
                 pos[i] = min(lo + ((hi - lo) * (uint32_t)(i + 1)) / 9u, n ? n - 1u : 0u);
-                val[i] = n ? p[pos[i]] : 0xFFFFFFFFu;
+                val[i] = n ? p[(uint64_t)pos[i] * 4] : 0xFFFFFFFFu;
               }
               uint32_t nlo = lo, nhi = hi;
 #pragma unroll
               for (int i = 0; i < 8; i++) {
-                if (val[i] < hi_doc) nlo = max(nlo, pos[i] + 1u); else nhi = min(nhi, pos[i]);
+                if (val[i] < hi_doc) nlo = max(nlo, pos[i]); else nhi = min(nhi, pos[i]);
               }
-              lo = min(nlo, nhi); hi = nhi;
+              hi = nhi; lo = min(nlo, nhi);
             }
           }
-          const uint32_t c_start = prev_lo[r] >> 2, c_end = (hi + 3) >> 2;   // rounded outwards to whole chunks
+          const uint32_t c_start = prev_lo[r], c_end = hi;
           ls_r[r] = full_ls[r] + c_start;
           ln_r[r] = c_end > c_start ? c_end - c_start : 0u;
           prev_lo[r] = lo;
@@ -1452,7 +1479,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           typedef u32x4v u32x4;
           u32x4 v[SG_UNROLL], vn[SG_UNROLL];
           uint32_t live[SG_UNROLL], liven[SG_UNROLL];
-          u32x16 was;
           uint32_t next_row = 0;
           auto fetch = [&](u32x4 (&vv)[SG_UNROLL], uint32_t (&lv)[SG_UNROLL]) {
 #pragma unroll
@@ -1467,13 +1493,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           // ping-pong between two register sets: the next batch's loads are in flight while one is counted
           auto process = [&](u32x4 (&qv)[SG_UNROLL], const uint32_t (&pl)[SG_UNROLL], uint32_t row0) {
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) :: "memory");
-            const uint4 pv[SG_UNROLL] = {make_uint4(qv[0].x, qv[0].y, qv[0].z, qv[0].w), make_uint4(qv[1].x, qv[1].y, qv[1].z, qv[1].w),
-                                         make_uint4(qv[2].x, qv[2].y, qv[2].z, qv[2].w), make_uint4(qv[3].x, qv[3].y, qv[3].z, qv[3].w)};
-            uint64_t any = 0;
-            if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x), "v"(pv[2].x), "v"(pv[3].x));
-            else any = u8 ? count_rows<true>(pv, pl, amask, cbase, dummy_lane, Tm1, was) : count_rows<false>(pv, pl, amask, cbase, dummy_lane, Tm1, was);
-            DBG_COUNT(1, 1)
-            if (any) { PH(5) flagged(pv, pl, was, row0, Tm1); PH(6) }
+#pragma unroll
+            for (int h = 0; h < SG_UNROLL / SG_SUB; h++) {     // SG_SUB rows = 14 postings per LDS round trip
+              const uint4 pv[SG_SUB] = {make_uint4(qv[2 * h].x, qv[2 * h].y, qv[2 * h].z, qv[2 * h].w),
+                                        make_uint4(qv[2 * h + 1].x, qv[2 * h + 1].y, qv[2 * h + 1].z, qv[2 * h + 1].w)};
+              const uint32_t sl[SG_SUB] = {pl[2 * h], pl[2 * h + 1]};
+              u32x16 pp, was;
+              uint32_t mx = 0;
+              uint64_t any = 0;
+              if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x));
+              else any = u8 ? count_rows<true>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx) : count_rows<false>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx);
+              DBG_COUNT(1, 1)
+              if (any) { PH(5) flagged(pp, sl, was, mx, row0 + (uint32_t)(SG_SUB * h), Tm1); PH(6) }
+            }
           };
           // fetches are unconditional (rows past the last are dead rows: they load chunk 0): every process() has the four
           // loads of the following batch behind its own
@@ -1514,10 +1546,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             const uint32_t c = c0 + lane;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < n) v = post4[s + c];
+            u32x8v pc;
+            decode_chunk(v, pc, 0);
 #pragma nounroll
-            for (int e = 0; e < 4; e++) {
-              const uint32_t d = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
-              const uint32_t dprev = e == 1 ? v.x : e == 2 ? v.y : v.z;
+            for (int e = 0; e < SG_PPC; e++) {
+              const uint32_t d = pc[e];
+              const uint32_t dprev = pc[e ? e - 1 : 0];
               bool flag = false;
               if (c < n && !(e > 0 && d == dprev)) {
                 const uint32_t bk = d & ((1u << lg) - 1u);
