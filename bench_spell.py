@@ -1,10 +1,10 @@
 """BASELINE config 5: the spellchecker caller — SpellChecker.Predict over a 50M-token language model
 (python bench.py --config cfg5 [--gpus N --steps K --warmup W]).
 
-A "step" is one sg_spell_predict_batch call over one batch of 65,536 queries per GPU: host word tokeniser + word ids,
-then five launches on one stream (NGramModel.Next, LM-ranked autocomplete, selection, Cosine fuzzy top-up, merge +
-stable re-rank).  The boundary of this path hands host buffers over (there is no device-resident entry point for
-Predict), so `value` is PCIe- and host-tokeniser-inclusive — said in the JSON.  The model is synthetic
+A "step" is one sg_spell_predict_batch_device call over one batch of 65,536 queries per GPU, queries and result rows resident
+in HBM: six launches on one stream (word tokeniser + word ids, NGramModel.Next, LM-ranked autocomplete, selection, Cosine
+fuzzy top-up, merge + stable re-rank).  The host-buffer entry point (sg_spell_predict_batch, PCIe-inclusive) is timed beside
+it and reported as `host_buffers`, never as `value`.  The model is synthetic
 (tools/make_synthetic_lm.py: Zipf words, 1M-word vocabulary, ~50M tokens incl. sentence markers), written in the
 reference's production formats (<name>.lm + <name>.cdb) and loaded through RetrieveLMFromBinary's twin; per GPU: a
 replica of the vocabulary's fuzzy index and of the LM arrays (weak scaling, no collective).
@@ -62,31 +62,23 @@ def main(args):
     log("model loaded + vocabulary index built/uploaded in %.1fs: %d words, %s" % (time.time() - t0, len(lm), st))
 
     # queries: two context words of a corpus position + the next word cut to a prefix (2 of 3) or with a typo (1 of 3)
-    T, words = info["corpus_sample"], info["word_list"]
-    rng = np.random.Generator(np.random.PCG64(100 + rank))
-    markers = (info["start_id"], info["end_id"])
+    seeds = iter(range(100 + 1000 * rank, 100 + 1000 * rank + 1000))
 
     def make_batch():
-        out = []
-        while len(out) < n_q:
-            p = int(rng.integers(2, len(T)))
-            a, b, c = int(T[p - 2]), int(T[p - 1]), int(T[p])
-            if a in markers or b in markers or c in markers:
-                continue
-            w = words[c]
-            if len(out) % 3 == 2 and len(w) > 3:
-                j = int(rng.integers(1, len(w)))
-                w = w[:j] + bytes([ord("a") + int(rng.integers(0, 26))]) + w[j + 1:]
-            else:
-                w = w[:max(2, (len(w) * 2 + 2) // 3)]
-            out.append(words[a] + b" " + words[b] + b" " + w)
-        return pack_strings(out)
+        return pack_strings(make_synthetic_lm.make_queries(info, n_q, next(seeds)))
 
     batches = [make_batch() for _ in range(n_b)]
     log("%d batches of %d queries" % (n_b, n_q))
+    row = top_k + 1
+    d_q = [torch.from_numpy(qb).to(dev) for qb, _ in batches]
+    d_o = [torch.from_numpy(qo.view(np.int64)).to(dev) for _, qo in batches]
+    d_ids = [torch.zeros((n_q, row), dtype=torch.int32, device=dev) for _ in range(n_b)]
+    d_cnt = [torch.zeros(n_q, dtype=torch.int32, device=dev) for _ in range(n_b)]
+    stream = torch.cuda.current_stream(dev)
 
-    def step(b):
-        return sc.predict_batch(blob=batches[b][0], offs=batches[b][1], top_k=top_k, similarity=sim)
+    def step(b):       # device-resident: queries and result rows in HBM, the word tokeniser on the device too
+        sc.predict_batch_device(d_q[b].data_ptr(), d_o[b].data_ptr(), n_q, int(batches[b][1][-1]), top_k, sim, d_ids[b].data_ptr(), d_cnt[b].data_ptr(),
+                                stream=stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -97,22 +89,40 @@ def main(args):
     for i in range(args.warmup):
         step(i % n_b)
     barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for i in range(args.steps):
-        res = step(i % n_b)
+        ev[i][0].record(stream)
+        step(i % n_b)
+        ev[i][1].record(stream)
     barrier()
     elapsed = time.perf_counter() - t_start
+    gpu_ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    for b in range(n_b):
+        step(b)
+    torch.cuda.synchronize(dev)
+    res = (d_ids[0].cpu().numpy().view(np.uint32), d_cnt[0].cpu().numpy().view(np.uint32))
+    # the host-buffer entry point (what a cgo caller uses): PCIe-inclusive, never `value`; same rows
+    host_rate = None
+    if rank == 0 and world == 1:
+        h_ids, h_cnt = sc.predict_batch(blob=batches[0][0], offs=batches[0][1], top_k=top_k, similarity=sim)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sc.predict_batch(blob=batches[0][0], offs=batches[0][1], top_k=top_k, similarity=sim)
+        host_rate = 3 * n_q / (time.perf_counter() - t0)
+        if not (np.array_equal(h_cnt, res[1]) and np.array_equal(h_ids, res[0])):
+            raise SystemExit("sg_spell_predict_batch (host buffers) and sg_spell_predict_batch_device disagree")
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         t0 = time.time()
         olm = oracle.OracleLM(binary=os.path.join(d, "synth.lm"), dictionary=os.path.join(d, "synth.cdb"))
-        oix = oracle.OracleIndex(words, ngram_size=sc.description.ngram_size, wrap=sc.description.wrap, pad=sc.description.pad,
+        oix = oracle.OracleIndex(info["word_list"], ngram_size=sc.description.ngram_size, wrap=sc.description.wrap, pad=sc.description.pad,
                                  alphabet=sc.description.alphabet)
         log("oracle model + index in %.1fs" % (time.time() - t0))
         cores = os.cpu_count() or 1
@@ -128,7 +138,7 @@ def main(args):
         cpu = {"value": n_s / dt, "unit": "predictions/s", "cores": cores, "kind": "port",
                "sample": "first %d queries of batch 0, same model; C++ restatement of pkg/spellchecker + pkg/lm (oracle/), OpenMP across queries" % n_s,
                "one_thread": {"value": n_1 / dt1, "unit": "predictions/s", "cores": 1, "sample": "first %d queries" % n_1}}
-        gi, gc = step(0)
+        gi, gc = res
         valid = np.arange(top_k + 1)[None, :] < np.minimum(oc, top_k + 1)[:, None]
         same = bool(np.array_equal(gc[:n_s], oc) and np.array_equal(gi[:n_s][valid], oi[valid]))
         parity = {"checked_queries": int(n_s), "bit_exact": same}
@@ -146,26 +156,92 @@ def main(args):
         _lib.check(_lib.lib().sg_autocomplete_algorithmic_bytes(sc.index._h, lb.ctypes.data, lo.ctypes.data, len(last), top_k, C.byref(tot)))
         alg_auto = tot.value / len(last) * n_q
         ms = elapsed / args.steps * 1e3
+        kernels = None
+        under_profiler = any(kk.startswith(("ROCPROF", "ROCP_")) for kk in os.environ)
+        if world == 1 and args.traffic != "none" and not under_profiler:
+            kernels = _live_kernels(args, tokens, n_q, top_k, sim, n_b, log)
+        lm_k = (kernels or {}).get("lm_autocomplete")
+        roof = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel": "sg_search_kernel_t<false, true, ...> (LM-ranked autocomplete: the launch with the most bytes)",
+                "achieved": lm_k["gbps"] if lm_k else None, "frac": lm_k["gbps"] / 8000.0 if lm_k else None,
+                "traffic": lm_k["traffic"] if lm_k else None,
+                "traffic_source": lm_k["source"] if lm_k else "MISSING: no live PMC pass (N > 1, --traffic none, rocprofv3 absent or under a profiler)",
+                "effective_gbps": alg_auto / (lm_k["ms"] * 1e-3) / 1e9 if lm_k else None,
+                "effective_frac": alg_auto / (lm_k["ms"] * 1e-3) / 1e9 / 8000.0 if lm_k else None,
+                "algorithmic_bytes_per_launch": alg_auto, "step_gpu_ms_avg": gpu_ms, "kernels": kernels,
+                "note": "per kernel of one Predict step (rocprofv3 child pass of this run): ms = average dispatch duration, traffic = FETCH_SIZE x 1024 x 2 "
+                        "(gfx950 correction), gbps = traffic / ms; achieved / frac = the LM-ranked autocomplete launch; effective_* = its algorithmic bytes "
+                        "(sg_autocomplete_algorithmic_bytes, extrapolated from 8192 queries) over the same duration"}
         out = {
             "metric": "spellchecker predictions/sec (topK=%d, Cosine>=%.2g top-up) on a %dM-token LM, %dk-word vocabulary" % (top_k, sim, round(info["tokens"] / 1e6), len(lm) // 1000),
             "value": world * n_q * args.steps / elapsed, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (posting / counter / count-search work)", "data": "synthetic",
             "config": {"workload": "SpellChecker.Predict: %d-token synthetic corpus -> 3-gram LM (%d words, %d bigrams, %d trigrams) in the reference's .lm/.cdb formats; "
-                                   "%d queries per GPU per step ('w1 w2 prefix', one third with a typo), %d batches in rotation; host buffers in and out (PCIe + host tokeniser inside the timed region)"
+                                   "%d queries per GPU per step ('w1 w2 prefix', one third with a typo), %d batches in rotation; queries and result rows resident in HBM "
+                                   "(sg_spell_predict_batch_device: word tokeniser, word ids, Next, both searches, merge on the device)"
                                    % (info["tokens"], len(lm), info["bigrams"], info["trigrams"], n_q, n_b),
                        "baseline_config": "cfg5", "parallelism": "query-sharded x%d, vocabulary index + LM replica per GPU" % world,
                        "index": {"postings": st["n_postings"], "terms": st["n_terms"], "device_bytes": st["device_bytes"]},
                        "predictions_per_query": float(np.minimum(res[1], top_k + 1).mean())},
-            "roofline": {"bound": "hbm", "achieved": alg_auto / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_auto / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                         "note": "algorithmic bytes of the LM-ranked autocomplete launch only (sg_autocomplete_algorithmic_bytes, extrapolated from 8192 queries) over the "
-                                 "WHOLE step time incl. host tokeniser, PCIe and the four other launches: a lower bound of that kernel's rate; per-kernel times in profiles/r02_cfg5_*",
-                         "algorithmic_bytes_per_launch": alg_auto},
+            "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if host_rate:
+            out["host_buffers"] = {"value": host_rate, "unit": "predictions/s",
+                                   "note": "sg_spell_predict_batch: pageable host buffers in and out over PCIe, synchronous (never `value`)"}
         if parity:
             out["parity_vs_oracle"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _live_kernels(args, tokens, n_q, top_k, sim, n_b, log):
+    """Per-kernel duration and HBM traffic of a Predict step, measured now: this benchmark again, as a child under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace`.  -> {name: {ms, traffic, gbps, launches, source}} or None"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        return None
+    tmp = tempfile.mkdtemp(prefix="sg_pmc5_", dir="/tmp")
+    cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--dict-size", str(tokens), "--queries", str(n_q), "--topk", str(top_k),
+           "--similarity", repr(sim), "--batches", str(n_b), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--traffic", "none"]
+    names = {"spell_tokenize_kernel": "tokenize", "spell_next_kernel": "lm_next", "sg_search_kernel_t<false, true,": "lm_autocomplete",
+             "spell_select_kernel": "select", "sg_search_kernel_t<false, false,": "fuzzy_top_up", "spell_merge_kernel": "merge",
+             "query_order_": "query_order"}
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            log("live PMC pass failed (%d): %s" % (r.returncode, (r.stderr or "")[-300:]))
+            return None
+        acc = {}
+        for path in sorted(glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)):
+            for rowd in csv.DictReader(open(path)):
+                if rowd.get("Counter_Name") != "FETCH_SIZE":
+                    continue
+                for pat, nm in names.items():
+                    if pat in rowd["Kernel_Name"]:
+                        a = acc.setdefault(nm, [0, 0.0, 0.0])
+                        a[0] += 1
+                        a[1] += (float(rowd["End_Timestamp"]) - float(rowd["Start_Timestamp"])) * 1e-6
+                        a[2] += float(rowd["Counter_Value"]) * 1024 * 2
+                        break
+        out = {}
+        steps = max(1, acc.get("merge", [4])[0])
+        for nm, (n, ms, by) in acc.items():
+            per_ms, per_b = ms / steps, by / steps
+            out[nm] = {"ms": per_ms, "traffic": per_b, "gbps": per_b / (per_ms * 1e-3) / 1e9 if per_ms else None, "launches_per_step": n / steps,
+                       "source": "live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass, %d steps; per step" % steps}
+        log("live per-kernel pass (%.0fs): %s" % (time.time() - t0, {k: (round(v["ms"], 3), round(v["traffic"] / 1e6, 1)) for k, v in out.items()}))
+        return out
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
+        log("live PMC pass failed: %r" % (exc,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -202,6 +202,12 @@ int sg_spell_index_build(const sg_lm* lm, const sg_desc* desc, int device, sg_in
  * sg_spell_index_build (or be any uploaded index over the model's vocabulary in id order). */
 int sg_spell_predict_batch(sg_index* index, sg_lm* lm, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
                            uint32_t top_k, double similarity, uint32_t* out_ids, uint32_t* out_counts);
+/* The same with every buffer in the HBM of the GPU that holds `index`'s primary replica, asynchronous on `stream`: d_q =
+ * the queries (q_bytes bytes), d_offs = n_q + 1 uint64 offsets starting at 0, d_out_ids = [n_q][top_k + 1] uint32,
+ * d_out_counts = [n_q] uint32.  The word tokeniser, the word ids and LanguageModel.Next's wrap / trim rules run on the
+ * device too (spellchecker.go:40-64,94-107; language_model.go:100-112): nothing of a query touches the host. */
+int sg_spell_predict_batch_device(sg_index* index, sg_lm* lm, const void* d_q, const void* d_offs, uint32_t n_q, uint64_t q_bytes,
+                                  uint32_t top_k, double similarity, void* d_out_ids, void* d_out_counts, void* stream);
 
 /* ---- introspection (tests, bench.py) ---------------------------------------------------- */
 typedef struct sg_stats {

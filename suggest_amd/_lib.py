@@ -21,7 +21,7 @@ EXPORTS = [
     "sg_autocomplete_batch_device", "sg_index_retain", "sg_index_release", "sg_last_error", "sg_index_stats",
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
-    "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch",
+    "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch", "sg_spell_predict_batch_device",
     "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one",
     "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort",
 ]
@@ -100,6 +100,7 @@ def lib():
     if hasattr(L, "sg_lm_tokenize"): L.sg_lm_tokenize.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32]
     if hasattr(L, "sg_spell_index_build"): L.sg_spell_index_build.argtypes = [vp, C.POINTER(SgDesc), i32, C.POINTER(vp)]
     if hasattr(L, "sg_spell_predict_batch"): L.sg_spell_predict_batch.argtypes = [vp, vp, vp, vp, u32, u32, dbl, vp, vp]
+    if hasattr(L, "sg_spell_predict_batch_device"): L.sg_spell_predict_batch_device.argtypes = [vp, vp, vp, vp, u32, C.c_uint64, u32, dbl, vp, vp, vp]
     if hasattr(L, "sg_index_retain"): L.sg_index_retain.argtypes = [vp]
     if hasattr(L, "sg_index_retain"): L.sg_index_retain.restype = None
     if hasattr(L, "sg_index_release"): L.sg_index_release.argtypes = [vp]

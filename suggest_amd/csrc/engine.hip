@@ -119,6 +119,7 @@ struct BatchArgs {
   DeviceIndex ix;
   const uint8_t* q_blob;
   const uint64_t* q_offs;
+  const uint32_t* q_len;   // null: query i is q_blob[q_offs[i] .. q_offs[i + 1]); else q_blob[q_offs[i] .. q_offs[i] + q_len[i]) (Predict's last words)
   uint32_t* out_ids;
   double* out_scores;   // null in autocomplete mode
   uint32_t* out_counts;
@@ -875,8 +876,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     __syncthreads();
   }
   do {   // one query (or one part of one): `break` leaves it
-  const uint64_t qb = a.q_offs[qi], qe = a.q_offs[qi + 1];
+  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
   const uint32_t lm_from = kLM ? a.lm_from[qi] : 0u, lm_to = kLM ? a.lm_to[qi] : 0u;
+  // The continuations of the query's context, one (word << 32 | count) per lane when there are at most 64 of them (the
+  // usual case: a bigram context of a 50 M-token model has a handful): ScoreNext of a candidate is then a compare across
+  // the wave instead of a search in HBM per prefix match — that search, one dependent round trip per match inside the
+  // serial emit loop, was what the LM-ranked autocomplete spent its time on (0.05 of the HBM peak).
+  const bool lm_small = kLM && lm_to - lm_from <= 64u;
+  uint32_t lm_w = 0xFFFFFFFFu, lm_c = 0u;
+  if (kLM && lm_small && lm_from + (uint32_t)lane < lm_to) { const uint64_t v = a.lm_values[lm_from + (uint32_t)lane]; lm_w = (uint32_t)(v >> 32); lm_c = (uint32_t)v; }
   uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
@@ -1025,8 +1033,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t lo_doc = 0, hi_doc = 0xFFFFFFFFu;                  // docID range of the current pass (whole range outside pass groups)
     // (d = the ORIGINAL docID: the top-k's order, the LM's word ids and the results are in the caller's numbering)
     auto offer = [&](uint32_t d, int overlap, int w) {
-      if (kLM)                                                              // lmCollector: score = ScoreNext(doc), monotone in the count
-        topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
+      if (kLM) {                                                            // lmCollector: score = ScoreNext(doc), monotone in the count
+        uint32_t c;
+        if (lm_small) { const uint64_t m = ballot(lm_w == d); c = m ? readlane(lm_c, __builtin_ctzll(m)) : 0u; }
+        else c = d_lm_count(a.lm_values, lm_from, lm_to, d, lane);
+        topk_insert(tk, (uint64_t)c, d, lane);
+      }
       else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }   // score = -docID, collector.go:104-106
       else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
     };
@@ -1681,7 +1693,114 @@ struct SpellArgs {
   const uint32_t* f_ids; const uint32_t* f_cnt;   // fuzzy rows [n_q][top_k] (rows of the selected queries only)
   uint32_t* sel; uint32_t* sel_n;
   uint32_t* out_ids; uint32_t* out_counts;        // [n_q][top_k + 1]
+  // ---- spell_tokenize_kernel: the word tokeniser and the word ids, on the device ----
+  const uint8_t* q_blob; const uint64_t* q_offs;  // the queries
+  uint32_t* ctx_w; uint8_t* ctx_len_w; uint8_t* has_word_w;   // out (what ctx / ctx_len / has_word point at)
+  uint8_t* w_blob; uint64_t* w_off; uint32_t* w_len;          // out: the last word of query i is w_blob[w_off[i] .. + w_len[i]), w_off[i] = 2 * q_offs[i]
+  const uint2* alpha_ranges; uint32_t n_alpha_ranges;          // the model alphabet's runes >= 128 as inclusive ranges, ascending
+  uint64_t alpha_ascii[2];                                     // ... and below 128 as a bitmap
+  const uint32_t* lower_from; const uint32_t* lower_to; uint32_t n_lower;   // simple lower-case pairs (the index replica's)
+  const uint4* vocab;                                          // open addressing: {hash lo, hash hi, word id, -}, id 0xFFFFFFFF = empty
+  uint32_t vocab_mask;
+  const uint8_t* vocab_bytes; const uint32_t* vocab_off;       // the words, id order (a hit is confirmed byte by byte)
+  uint32_t start_symbol;
 };
+
+__device__ __forceinline__ bool d_lm_alpha_has(const SpellArgs& p, uint32_t r) {
+  if (r < 128u) return (p.alpha_ascii[r >> 6] >> (r & 63u)) & 1ull;
+  uint32_t lo = 0, hi = p.n_alpha_ranges;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p.alpha_ranges[mid].y < r) lo = mid + 1; else hi = mid; }
+  return lo < p.n_alpha_ranges && p.alpha_ranges[lo].x <= r;
+}
+__device__ __forceinline__ uint32_t d_lm_lower(const SpellArgs& p, uint32_t r) {
+  if (r < 0x80u) return (r - 'A' < 26u) ? r + 32u : r;
+  uint32_t lo = 0, hi = p.n_lower;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p.lower_from[mid] < r) lo = mid + 1; else hi = mid; }
+  return (lo < p.n_lower && p.lower_from[lo] == r) ? p.lower_to[lo] : r;
+}
+__device__ __forceinline__ uint64_t d_word_hash_step(uint64_t h, uint32_t byte) { return (h ^ (uint64_t)byte) * 0x100000001B3ull; }   // FNV-1a
+#define SG_WORD_HASH_SEED 0xCBF29CE484222325ull
+__device__ uint32_t d_word_id(const SpellArgs& p, uint64_t h, const uint8_t* w, uint32_t n) {
+  h = d_mix64(h);
+  for (uint32_t s = (uint32_t)h & p.vocab_mask;; s = (s + 1u) & p.vocab_mask) {
+    const uint4 e = p.vocab[s];
+    if (e.z == 0xFFFFFFFFu) return kUnknownWord;
+    if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) {
+      const uint32_t o0 = p.vocab_off[e.z], o1 = p.vocab_off[e.z + 1u];
+      bool same = o1 - o0 == n;
+      for (uint32_t i = 0; same && i < n; i++) same = p.vocab_bytes[o0 + i] == w[i];
+      if (same) return e.z;
+    }
+  }
+}
+
+// SpellChecker.Predict's host steps (spellchecker.go:40-64,94-107; language_model.go:100-112), one thread per query: the word
+// tokeniser (strings.ToLower, strings.Trim(" "), maximal runs of alphabet runes — pkg/analysis word tokenizer as the model
+// builds it), the last word, the ids of the words before it (the vocabulary hash, hits confirmed on the bytes), and the
+// wrap / trim rules of LanguageModel.Next.  The last word is written lower-cased into the query's slot of w_blob (two
+// bytes of slot per query byte: a lower-case mapping can lengthen a rune's encoding, 2 -> 3 bytes at most); every token
+// is written there from the slot's start, so what is left at the end is the last one.
+__global__ __launch_bounds__(256) void spell_tokenize_kernel(const SpellArgs p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_q) return;
+  const uint64_t o0 = p.q_offs[i], o1 = p.q_offs[i + 1];
+  const uint8_t* q = p.q_blob + o0;
+  uint32_t a = 0, b = (uint32_t)(o1 - o0);
+  while (a < b && q[a] == ' ') a++;                            // (U+0020 is the byte 0x20 and nothing else)
+  while (b > a && q[b - 1] == ' ') b--;
+  uint8_t* slot = p.w_blob + 2 * o0;
+  const uint32_t N = p.order;
+  uint32_t first[8], last[8];                                  // the first / the last N - 1 context ids (N <= 8)
+  uint32_t n_ctx = 0, n_tok = 0, pending = kUnknownWord;
+  uint32_t wl = 0;                                             // bytes of the token in progress
+  uint32_t last_len = 0;                                       // ... of the last finished one (its bytes stay in the slot until the next starts)
+  uint64_t h = SG_WORD_HASH_SEED;
+  auto end_token = [&]() {
+    if (wl == 0u) return;
+    if (n_tok) {                                               // the token before this one was not the last word: it is context
+      if (n_ctx < 8u) first[n_ctx] = pending;
+      last[n_ctx & 7u] = pending;
+      n_ctx++;
+    }
+    pending = d_word_id(p, h, slot, wl);
+    n_tok++;
+    last_len = wl;
+    wl = 0u;
+  };
+  for (uint32_t pos = a; pos < b;) {
+    uint32_t adv;
+    const uint32_t r = d_lm_lower(p, d_next_rune(q + pos, b - pos, &adv));
+    pos += adv;
+    if (!d_lm_alpha_has(p, r)) { end_token(); continue; }
+    if (wl == 0u) h = SG_WORD_HASH_SEED;                       // a new token, written from the slot's start
+    uint8_t enc[4];
+    const uint32_t w = d_width(r);
+    if (w == 1u) enc[0] = (uint8_t)r;
+    else if (w == 2u) { enc[0] = (uint8_t)(0xC0u | (r >> 6)); enc[1] = (uint8_t)(0x80u | (r & 0x3Fu)); }
+    else if (w == 3u) { enc[0] = (uint8_t)(0xE0u | (r >> 12)); enc[1] = (uint8_t)(0x80u | ((r >> 6) & 0x3Fu)); enc[2] = (uint8_t)(0x80u | (r & 0x3Fu)); }
+    else { enc[0] = (uint8_t)(0xF0u | (r >> 18)); enc[1] = (uint8_t)(0x80u | ((r >> 12) & 0x3Fu)); enc[2] = (uint8_t)(0x80u | ((r >> 6) & 0x3Fu)); enc[3] = (uint8_t)(0x80u | (r & 0x3Fu)); }
+    for (uint32_t j = 0; j < w; j++) { slot[wl + j] = enc[j]; h = d_word_hash_step(h, enc[j]); }
+    wl += w;
+  }
+  end_token();
+  p.w_off[i] = 2 * o0;
+  p.has_word_w[i] = n_tok ? 1 : 0;
+  uint8_t cl = 0;
+  uint32_t seq[8];
+  uint32_t n_seq = 0;
+  if (n_ctx) {                                                 // spellchecker.go:94-107: no context, no scorer
+    // language_model.go:100-112
+    if (n_ctx + 1u < N) { seq[n_seq++] = p.start_symbol; for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = first[t]; }
+    else if (n_ctx > N) { for (uint32_t t = n_ctx - (N - 1u); t < n_ctx; t++) seq[n_seq++] = last[t & 7u]; }
+    else if (n_ctx == N) { for (uint32_t t = 0; t + 1u < N; t++) seq[n_seq++] = first[t]; }   // (sic) keeps the FIRST order-1 words
+    else { for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = first[t]; }
+    if (n_seq == 0u || n_seq >= N) cl = 0xFF;                  // ngram_model.go:65-67: an error
+    else cl = (uint8_t)n_seq;
+  }
+  p.ctx_len_w[i] = cl;
+  for (uint32_t t = 0; t < 8u; t++) p.ctx_w[(uint64_t)i * 8u + t] = (cl != 0xFF && t < n_seq) ? seq[t] : 0u;
+  p.w_len[i] = last_len;
+}
 
 __global__ void spell_next_kernel(const SpellArgs p) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1782,26 +1901,28 @@ __global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
 // left to the atomics; rows are written by query index, so the results do not depend on it.
 // ctl: [0] = n_q (BatchArgs::q_sel_n), [4 .. 260) histogram, [260 .. 516) cursors — zeroed by the host before (1).
 #define SG_ORDER_CTL_WORDS 516
-__device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, uint32_t i, int shortest_first) {
-  const uint32_t len = (uint32_t)min((unsigned long long)(q_offs[i + 1] - q_offs[i]), 255ull);
+__device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, const uint32_t* q_len, uint32_t i, int shortest_first) {
+  const uint32_t len = q_len ? min(q_len[i], 255u) : (uint32_t)min((unsigned long long)(q_offs[i + 1] - q_offs[i]), 255ull);
+  // (Predict's last words: a query without one has nothing to search and goes last either way)
+  if (q_len && len == 0u) return 255u;
   return shortest_first ? len : 255u - len;
 }
-__global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, uint32_t n_q, int shortest_first, uint32_t* ctl) {
+__global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* ctl) {
   __shared__ uint32_t hist[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
   __syncthreads();
-  if (i < n_q) atomicAdd(&hist[d_order_bin(q_offs, i, shortest_first)], 1u);
+  if (i < n_q) atomicAdd(&hist[d_order_bin(q_offs, q_len, i, shortest_first)], 1u);
   __syncthreads();
   if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
   if (i == 0u) ctl[0] = n_q;
 }
-__global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl) {
+__global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl) {
   __shared__ uint32_t hist[256], start[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
   __syncthreads();
-  const uint32_t bin = i < n_q ? d_order_bin(q_offs, i, shortest_first) : 0u;
+  const uint32_t bin = i < n_q ? d_order_bin(q_offs, q_len, i, shortest_first) : 0u;
   if (i < n_q) atomicAdd(&hist[bin], 1u);
   if (tid < 256u) start[tid] = ctl[4 + tid];
   __syncthreads();

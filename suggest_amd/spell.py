@@ -135,6 +135,11 @@ class SpellChecker:
                                                      n, int(top_k), float(similarity), ids.ctypes.data, cnt.ctypes.data))
         return ids, cnt
 
+    def predict_batch_device(self, d_blob, d_offs, n_q, q_bytes, top_k, similarity, d_ids, d_counts, stream=0):
+        """sg_spell_predict_batch_device: raw device pointers (torch tensors' data_ptr()), asynchronous on `stream`"""
+        _lib.check(_lib.lib().sg_spell_predict_batch_device(self.index._h, self.model._h, d_blob, d_offs, int(n_q), int(q_bytes), int(top_k),
+                                                            float(similarity), d_ids, d_counts, stream))
+
     def Predict(self, query, topK, similarity):
         ids, cnt = self.predict_batch([query], topK, similarity)
         c = int(cnt[0])

@@ -103,3 +103,50 @@ def test_cfg2_1m_whole_batch():
         b.check("jaccard", 0.5, 10, every=1)
     finally:
         b.gpu.close(); b.ora.close()
+
+
+def test_cfg5_spellchecker_50m_token_model(tmp_path_factory):
+    """BASELINE config 5 at its size: SpellChecker.Predict (pkg/spellchecker/spellchecker.go:40-92) over a 50 M-token
+    synthetic 3-gram model in the reference's own .lm / .cdb formats (tools/make_synthetic_lm.py: ~1 M-word vocabulary, ids
+    by count like `lm build-lm`), the vocabulary's fuzzy index + the LM arrays resident on the GPU.  A 65,536-query batch
+    ('w1 w2 prefix', one third with a typo in the last word) goes through sg_spell_predict_batch; 4,096 sampled queries are
+    compared with the oracle's Predict row by row (ids and order), the rest is held to the path's invariants."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_synthetic_lm
+    from suggest_amd.index import pack_strings
+    from suggest_amd.spell import LanguageModel, SpellChecker
+    tokens = int(os.environ.get("SG_TEST_LM_TOKENS", 50_000_000))
+    d = str(tmp_path_factory.mktemp("lm50m"))
+    info = make_synthetic_lm.make(d, tokens=tokens, vocab=1_000_000 if tokens >= 20_000_000 else max(1000, tokens // 40), verbose=False)
+    assert info["tokens"] >= tokens * 0.99
+    lm = LanguageModel(binary=os.path.join(d, "synth.lm"), dictionary=os.path.join(d, "synth.cdb"))
+    sc = SpellChecker(lm, device=0)
+    top_k, sim = 5, 0.5
+    queries = make_synthetic_lm.make_queries(info, N_Q, seed=4242)
+    qb, qo = pack_strings(queries)
+    ids, cnt = sc.predict_batch(blob=qb, offs=qo, top_k=top_k, similarity=sim)
+    assert ids.shape == (N_Q, top_k + 1)
+    real = cnt <= top_k + 1
+    assert real.mean() > 0.99 and int(cnt[real].sum()) > N_Q            # predictions were made
+    valid = np.arange(top_k + 1)[None, :] < np.where(real, cnt, 0)[:, None]
+    assert (ids[valid] < len(lm)).all()
+    srt = np.sort(np.where(valid, ids.astype(np.int64), -np.arange(1, top_k + 2)[None, :]), axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                            # no word twice in a row of predictions
+    rows = np.arange(0, N_Q, 16)
+    sb, so = _subset(qb, qo, rows)
+    olm = oracle.OracleLM(binary=os.path.join(d, "synth.lm"), dictionary=os.path.join(d, "synth.cdb"))
+    oix = oracle.OracleIndex(info["word_list"], ngram_size=sc.description.ngram_size, wrap=sc.description.wrap, pad=sc.description.pad,
+                             alphabet=sc.description.alphabet)
+    oi, oc = olm.predict_batch(oix, sb, so, top_k, sim, threads=os.cpu_count() or 1)
+    assert np.array_equal(cnt[rows], oc)
+    ov = np.arange(top_k + 1)[None, :] < np.minimum(oc, top_k + 1)[:, None]
+    assert np.array_equal(ids[rows][ov], oi[ov])
+    # the same rows through the sliced path (two slices on two streams is the default at this batch size) and in one slice
+    os.environ["SG_SPELL_SLICES"] = "1"
+    try:
+        ids1, cnt1 = sc.predict_batch(blob=qb, offs=qo, top_k=top_k, similarity=sim)
+    finally:
+        del os.environ["SG_SPELL_SLICES"]
+    assert np.array_equal(cnt1, cnt) and np.array_equal(ids1[valid], ids[valid])

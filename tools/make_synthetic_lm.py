@@ -130,6 +130,28 @@ def make(directory, tokens=50_000_000, vocab=1_000_000, zipf=1.07, seed=7, verbo
             "start_id": int(new_id[S_ID]), "word_list": wl}
 
 
+def make_queries(info, n_q, seed):
+    """cfg 5's query stream: two context words of a corpus position + the next word cut to a prefix (2 of 3) or with a typo
+    (1 of 3) -> list[bytes]"""
+    T, words = info["corpus_sample"], info["word_list"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    markers = (info["start_id"], info["end_id"])
+    out = []
+    while len(out) < n_q:
+        p = int(rng.integers(2, len(T)))
+        a, b, c = int(T[p - 2]), int(T[p - 1]), int(T[p])
+        if a in markers or b in markers or c in markers:
+            continue
+        w = words[c]
+        if len(out) % 3 == 2 and len(w) > 3:
+            j = int(rng.integers(1, len(w)))
+            w = w[:j] + bytes([ord("a") + int(rng.integers(0, 26))]) + w[j + 1:]
+        else:
+            w = w[:max(2, (len(w) * 2 + 2) // 3)]
+        out.append(words[a] + b" " + words[b] + b" " + w)
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("directory")
