@@ -5,6 +5,7 @@
 //
 // NOT compiled in this repository (no Go toolchain in the build image); shipped as the binding a
 // maintainer adds next to pkg/suggest.  Build: CGO_ENABLED=1, -I<repo>/include, -L<repo>/suggest_amd.
+// Written for the Go the reference builds with (go.mod: 1.13; golang:1.14 image): no unsafe.Slice, no generics.
 package suggesthip
 
 /*
@@ -53,11 +54,8 @@ func (b *Builder) Build() (suggest.NGramIndex, error) {
 		return nil, err
 	}
 	d := b.Description
-	alpha := make([]*C.char, len(d.Alphabet))
-	for i, a := range d.Alphabet {
-		alpha[i] = C.CString(a)
-		defer C.free(unsafe.Pointer(alpha[i]))
-	}
+	arr, freeAlpha := cstrings(d.Alphabet)
+	defer freeAlpha()
 	w0, w1, pad := C.CString(d.Wrap[0]), C.CString(d.Wrap[1]), C.CString(d.Pad)
 	defer C.free(unsafe.Pointer(w0))
 	defer C.free(unsafe.Pointer(w1))
@@ -65,78 +63,128 @@ func (b *Builder) Build() (suggest.NGramIndex, error) {
 	// the descriptor lives in C memory for the duration of the call (cgo pointer rules)
 	desc := (*C.sg_desc)(C.malloc(C.size_t(unsafe.Sizeof(C.sg_desc{}))))
 	defer C.free(unsafe.Pointer(desc))
-	arr := (**C.char)(C.malloc(C.size_t(len(alpha)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	defer C.free(unsafe.Pointer(arr))
-	copy(unsafe.Slice(arr, len(alpha)), alpha)
 	desc.ngram_size, desc.wrap_start, desc.wrap_end, desc.pad = C.uint32_t(d.NGramSize), w0, w1, pad
-	desc.alphabet, desc.n_alphabet = arr, C.uint32_t(len(alpha))
+	desc.alphabet, desc.n_alphabet = arr, C.uint32_t(len(d.Alphabet))
 
 	var h *C.sg_index
 	var bp *C.uint8_t
 	if len(blob) > 0 {
 		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
 	}
-	rc := C.int(C.SG_E_UNSUPPORTED)
-	if b.OnDevice {
-		rc = C.sg_index_build_device(bp, &offs[0], C.uint32_t(len(offs)-1), desc, C.int(b.Device), &h)
+	built := false
+	if b.OnDevice { // documents with more than 128 n-grams are beyond the device builder: SG_E_UNSUPPORTED, then the host's
+		runtime.LockOSThread()
+		rc := C.sg_index_build_device(bp, &offs[0], C.uint32_t(len(offs)-1), desc, C.int(b.Device), &h)
+		if rc != 0 && rc != C.SG_E_UNSUPPORTED {
+			err := fmt.Errorf("suggest_hip %d: %s", int(rc), C.GoString(C.sg_last_error()))
+			runtime.UnlockOSThread()
+			return nil, err
+		}
+		runtime.UnlockOSThread()
+		built = rc == 0
 	}
-	if rc == C.SG_E_UNSUPPORTED {
-		rc = C.sg_index_build(bp, &offs[0], C.uint32_t(len(offs)-1), desc, &h)
+	if !built {
+		if err := ccall(func() C.int { return C.sg_index_build(bp, &offs[0], C.uint32_t(len(offs)-1), desc, &h) }); err != nil {
+			return nil, err
+		}
 	}
-	if rc != 0 {
-		return nil, lastError(rc)
-	}
-	if rc := C.sg_index_upload(h, C.int(b.Device)); rc != 0 {
+	if err := ccall(func() C.int { return C.sg_index_upload(h, C.int(b.Device)) }); err != nil {
 		C.sg_index_release(h)
-		return nil, lastError(rc)
+		return nil, err
 	}
 	if len(b.Devices) > 0 {
 		devs := make([]C.int, len(b.Devices))
 		for i, d := range b.Devices {
 			devs[i] = C.int(d)
 		}
-		if rc := C.sg_index_replicate(h, &devs[0], C.uint32_t(len(devs))); rc != 0 {
+		if err := ccall(func() C.int { return C.sg_index_replicate(h, &devs[0], C.uint32_t(len(devs))) }); err != nil {
 			C.sg_index_release(h)
-			return nil, lastError(rc)
+			return nil, err
 		}
 	}
-	ix := &Index{h: h, reqs: make(chan *request, 4096)}
-	go ix.dispatch()
-	runtime.SetFinalizer(ix, func(i *Index) { C.sg_index_release(i.h) }) // cf. pkg/index/index_reader.go:49-51
+	e := &engine{h: h, reqs: make(chan *request, 4096), done: make(chan struct{})}
+	go e.dispatch() // holds the engine only: the Index stays collectable, its finalizer (or Close) stops the dispatcher
+	ix := &Index{e: e}
+	runtime.SetFinalizer(ix, func(i *Index) { i.Close() }) // cf. pkg/index/index_reader.go:49-51
 	return ix, nil
 }
 
 // Index is the GPU-resident NGramIndex.  Single-query calls (the reference's calling pattern: one Suggest per goroutine,
 // pkg/suggest/service_test.go:36-79) are coalesced HERE, in Go: a goroutine parks on a channel for a fraction of what a
 // blocked cgo call costs, so the C-side queue (sg_suggest_one) is left to C / C++ / Python callers.
+//
+// Life cycle: Service.AddIndex swaps indexes (service.go:78-91, the SIGHUP re-index path) and drops the old one.  The
+// dispatcher goroutine references only the inner engine, never the Index, so a dropped Index is finalized: Close stops
+// the dispatcher, which releases the handle — and with it the HBM replicas — once the batch in flight is answered.
+// Callers that know when an index goes should call Close themselves instead of waiting for the collector.
 type Index struct {
-	h    *C.sg_index
-	reqs chan *request
+	e    *engine
+	once sync.Once
+}
+
+type engine struct {
+	h      *C.sg_index
+	reqs   chan *request
+	done   chan struct{}
+	mu     sync.RWMutex // closed, and the retain of a call, are read under it: Close cannot slip in between
+	closed bool
+}
+
+var errClosed = errors.New("suggesthip: index is closed")
+
+// Close stops the dispatcher and gives the creator's reference back; queries in flight finish first (they hold their own).
+func (i *Index) Close() error {
+	i.once.Do(func() {
+		e := i.e
+		e.mu.Lock()
+		e.closed = true
+		close(e.reqs)
+		e.mu.Unlock()
+		runtime.SetFinalizer(i, nil)
+	})
+	return nil
+}
+
+// retain takes a reference for the duration of a C call (service.go:85-88 swaps indexes while queries run).
+func (e *engine) retain() error {
+	e.mu.RLock()
+	defer e.mu.RUnlock()
+	if e.closed {
+		return errClosed
+	}
+	C.sg_index_retain(e.h)
+	return nil
 }
 
 type request struct {
 	query      string
 	similarity float64
-	m          metric.Metric
 	code       C.int
 	k          int
 	resp       chan response
 }
 
 type response struct {
-	cands []suggest.Candidate
-	err   error
+	cands  []suggest.Candidate
+	status uint32 // SG_COUNT_* flag of THIS query (0: answered)
+	err    error
 }
 
 // dispatch runs whatever single-query requests are pending as one batch per distinct (metric, similarity, k): no timer —
-// an idle engine serves a lone request at once, a busy one finds the requests that arrived meanwhile.
-func (i *Index) dispatch() {
-	for first := range i.reqs {
+// an idle engine serves a lone request at once, a busy one finds the requests that arrived meanwhile.  Every request gets
+// ITS OWN outcome: a query the reference would panic or dead-lock on, or one past the engine's limits, fails its caller
+// only — in the caller's goroutine (see Suggest) — and never the others that happened to share its launch.
+func (e *engine) dispatch() {
+	defer func() {
+		C.sg_index_release(e.h) // the creator's reference: the handle goes when the last call in flight returns
+		close(e.done)
+	}()
+	for first := range e.reqs {
 		batch := []*request{first}
 	drain:
 		for len(batch) < 8192 {
 			select {
-			case r, ok := <-i.reqs:
+			case r, ok := <-e.reqs:
 				if !ok {
 					break drain
 				}
@@ -159,12 +207,12 @@ func (i *Index) dispatch() {
 			for j, r := range same {
 				qs[j] = r.query
 			}
-			res, err := i.SuggestBatch(qs, head.similarity, head.m, head.k)
+			res, status, err := e.suggestBatch(qs, head.similarity, head.code, head.k)
 			for j, r := range same {
 				if err != nil {
-					r.resp <- response{nil, err}
+					r.resp <- response{nil, 0, err}
 				} else {
-					r.resp <- response{res[j], nil}
+					r.resp <- response{res[j], status[j], nil}
 				}
 			}
 			batch = rest
@@ -174,7 +222,42 @@ func (i *Index) dispatch() {
 
 var respPool = sync.Pool{New: func() interface{} { return make(chan response, 1) }}
 
-func lastError(rc C.int) error { return fmt.Errorf("suggest_hip %d: %s", int(rc), C.GoString(C.sg_last_error())) }
+// ccall runs one C-ABI call and, on failure, reads its message: sg_last_error is thread-local, and a goroutine may move to
+// another OS thread between two cgo calls — so both happen with the goroutine pinned.
+func ccall(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := f(); rc != 0 {
+		return fmt.Errorf("suggest_hip %d: %s", int(rc), C.GoString(C.sg_last_error()))
+	}
+	return nil
+}
+
+// cstrings lays a []string out as a C array of C strings (no unsafe.Slice: the reference builds with Go 1.13/1.14).
+func cstrings(xs []string) (**C.char, func()) {
+	arr := (**C.char)(C.malloc(C.size_t(len(xs)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	sl := (*[1 << 28]*C.char)(unsafe.Pointer(arr))[: len(xs) : len(xs)]
+	for i, x := range xs {
+		sl[i] = C.CString(x)
+	}
+	return arr, func() {
+		for _, p := range sl {
+			C.free(unsafe.Pointer(p))
+		}
+		C.free(unsafe.Pointer(arr))
+	}
+}
+
+// statusError is what a query's SG_COUNT_* flag means to its caller.
+func statusError(status uint32, q int) error {
+	switch status {
+	case C.SG_COUNT_REF_DEADLOCK:
+		return fmt.Errorf("suggesthip: query %d: the reference dead-locks here (suggester.go:62, zero channel capacity)", q)
+	case C.SG_COUNT_TOO_LONG:
+		return fmt.Errorf("suggesthip: query %d has more than %d n-grams", q, int(C.SG_MAX_QUERY_TERMS))
+	}
+	return nil
+}
 
 // metricCode recovers the metric behaviourally: the Metric interface is opaque at this seam
 // (unexported types), but its four methods identify it on two probe points.
@@ -232,24 +315,43 @@ type constScorer float64
 func (s constScorer) Score(merger.MergeCandidate) float64 { return float64(s) }
 
 // Suggest implements suggest.Suggester (pkg/suggest/suggester.go:17-20): the request joins whatever other goroutines are
-// asking at the moment and is answered from their common launch.
+// asking at the moment and is answered from their common launch.  What the reference does on THIS query it does to THIS
+// caller: the panic of suggester.go:62 (negative channel capacity) is raised here, in the caller's goroutine, where it can
+// be recovered like the reference's; the dead-lock case and a query past the engine's limits come back as an error.
 func (i *Index) Suggest(query string, similarity float64, m metric.Metric, factory suggest.CollectorManagerFactory) ([]suggest.Candidate, error) {
 	code, err := metricCode(m)
 	if err != nil {
 		return nil, err
 	}
-	r := &request{query: query, similarity: similarity, m: m, code: code, k: topK(factory), resp: respPool.Get().(chan response)}
-	i.reqs <- r
+	e := i.e
+	r := &request{query: query, similarity: similarity, code: code, k: topK(factory), resp: respPool.Get().(chan response)}
+	e.mu.RLock()
+	if e.closed {
+		e.mu.RUnlock()
+		return nil, errClosed
+	}
+	e.reqs <- r
+	e.mu.RUnlock()
 	out := <-r.resp
 	respPool.Put(r.resp)
-	return out.cands, out.err
+	runtime.KeepAlive(i)
+	if out.err != nil {
+		return nil, out.err
+	}
+	if out.status == C.SG_COUNT_REF_PANIC {
+		panic("makechan: size out of range") // what pkg/suggest/suggester.go:62 does on this query
+	}
+	if err := statusError(out.status, 0); err != nil {
+		return nil, err
+	}
+	return out.cands, nil
 }
 
-// SuggestBatch is the additive API the GPU earns its keep on: one kernel launch for all queries.
-func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metric, k int) ([][]suggest.Candidate, error) {
-	code, err := metricCode(m)
-	if err != nil {
-		return nil, err
+// suggestBatch is one launch for all queries; status[q] carries query q's SG_COUNT_* flag (0: answered, cands[q] valid).
+func (e *engine) suggestBatch(queries []string, similarity float64, code C.int, k int) ([][]suggest.Candidate, []uint32, error) {
+	n := len(queries)
+	if n == 0 {
+		return nil, nil, nil
 	}
 	var blob []byte
 	offs := []C.uint64_t{0}
@@ -257,7 +359,6 @@ func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metr
 		blob = append(blob, q...)
 		offs = append(offs, C.uint64_t(len(blob)))
 	}
-	n := len(queries)
 	ids := make([]C.uint32_t, n*k)
 	scores := make([]C.double, n*k)
 	counts := make([]C.uint32_t, n)
@@ -265,69 +366,97 @@ func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metr
 	if len(blob) > 0 {
 		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
 	}
-	C.sg_index_retain(i.h) // the handle stays valid while this query is in flight (service.go:85-88 swaps indexes)
-	rc := C.sg_suggest_batch_multi(i.h, bp, &offs[0], C.uint32_t(n), code, C.double(similarity), C.uint32_t(k), &ids[0], &scores[0], &counts[0]) // one replica: the plain call
-	C.sg_index_release(i.h)
-	runtime.KeepAlive(i)
-	if rc != 0 {
-		return nil, lastError(rc)
+	if err := e.retain(); err != nil {
+		return nil, nil, err
+	}
+	err := ccall(func() C.int { // one replica: the plain call; several: contiguous slices, a worker thread per replica
+		return C.sg_suggest_batch_multi(e.h, bp, &offs[0], C.uint32_t(n), code, C.double(similarity), C.uint32_t(k), &ids[0], &scores[0], &counts[0])
+	})
+	C.sg_index_release(e.h)
+	if err != nil {
+		return nil, nil, err
 	}
 	out := make([][]suggest.Candidate, n)
+	status := make([]uint32, n)
 	for q := 0; q < n; q++ {
 		c := uint32(counts[q])
-		switch c {
-		case C.SG_COUNT_REF_PANIC:
-			panic("makechan: size out of range") // what pkg/suggest/suggester.go:62 does on this query
-		case C.SG_COUNT_REF_DEADLOCK, C.SG_COUNT_TOO_LONG:
-			return nil, fmt.Errorf("suggesthip: query %d cannot be answered (status %#x)", q, c)
+		if c >= C.SG_COUNT_LM_ERROR { // an SG_COUNT_* flag: no row
+			status[q] = c
+			continue
 		}
 		out[q] = make([]suggest.Candidate, c)
 		for j := uint32(0); j < c; j++ {
 			out[q][j] = suggest.Candidate{Key: uint32(ids[q*k+int(j)]), Score: float64(scores[q*k+int(j)])}
 		}
 	}
-	return out, nil
+	return out, status, nil
+}
+
+// SuggestBatch is the additive API the GPU earns its keep on: one kernel launch for all queries.  status[q] != 0 marks a
+// query without an answer (C.SG_COUNT_REF_PANIC / _REF_DEADLOCK: the reference panics / dead-locks on it; _TOO_LONG);
+// the other rows are valid — one bad query does not fail the batch.
+func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metric, k int) (cands [][]suggest.Candidate, status []uint32, err error) {
+	code, err := metricCode(m)
+	if err != nil {
+		return nil, nil, err
+	}
+	cands, status, err = i.e.suggestBatch(queries, similarity, code, k)
+	runtime.KeepAlive(i)
+	return
 }
 
 // Autocomplete implements suggest.Autocomplete (pkg/suggest/autocomplete.go:14-17) for ANY collector manager: the matching
-// documents (ascending docID, as the reference's segments deliver them) are replayed through the caller's own collector —
-// first-k (collector.go:48-115) stops after its limit, pkg/spellchecker's lmCollectorManager ranks them with its scorer.
-// The engine hands over at most SG_MAX_TOPK documents per query; a prefix matched by more cannot be served to a collector
-// that wants them all and is reported as an error rather than answered short.
+// documents, ascending docID, are replayed through the caller's own collector — first-k (collector.go:48-115) stops after
+// its limit, pkg/spellchecker's lmCollectorManager (spellchecker/collector.go:61-79) ranks every one of them with its
+// scorer.  The engine hands them over in pages (sg_autocomplete_one_from: the next autocompletePage docIDs at or above
+// first_doc), so a prefix with any number of matches is served in full; a collector that terminates ends the paging.
+const autocompletePage = 4096
+
 func (i *Index) Autocomplete(query string, factory suggest.CollectorManagerFactory) ([]suggest.Candidate, error) {
-	const limit = 1024 // SG_MAX_TOPK
+	e := i.e
 	blob := []byte(query)
-	ids := make([]C.uint32_t, limit)
-	var cnt C.uint32_t
+	ids := make([]C.uint32_t, autocompletePage)
 	var bp *C.uint8_t
 	if len(blob) > 0 {
 		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
 	}
-	C.sg_index_retain(i.h)
-	rc := C.sg_autocomplete_one(i.h, bp, C.uint32_t(len(blob)), C.uint32_t(limit), &ids[0], &cnt)
-	C.sg_index_release(i.h)
-	runtime.KeepAlive(i)
-	if rc != 0 {
-		return nil, lastError(rc)
-	}
-	if uint32(cnt) == C.SG_COUNT_TOO_LONG {
-		return nil, fmt.Errorf("suggesthip: query has more than 128 n-grams")
-	}
 	mgr := factory()
 	c := mgr.Create()
-	terminated := false
-	for j := 0; j < int(cnt); j++ {
-		if err := c.Collect(merger.NewMergeCandidate(uint32(ids[j]), 0)); err != nil {
-			if errors.Is(err, merger.ErrCollectionTerminated) {
-				terminated = true
-				break
-			}
+	first := uint32(0)
+paging:
+	for {
+		var cnt C.uint32_t
+		if err := e.retain(); err != nil {
 			return nil, err
 		}
+		err := ccall(func() C.int {
+			return C.sg_autocomplete_one_from(e.h, bp, C.uint32_t(len(blob)), C.uint32_t(first), C.uint32_t(autocompletePage), &ids[0], &cnt)
+		})
+		C.sg_index_release(e.h)
+		if err != nil {
+			return nil, err
+		}
+		if err := statusError(uint32(cnt), 0); err != nil {
+			return nil, err
+		}
+		n := int(cnt)
+		if n > autocompletePage {
+			n = autocompletePage
+		}
+		for j := 0; j < n; j++ {
+			if err := c.Collect(merger.NewMergeCandidate(uint32(ids[j]), 0)); err != nil {
+				if errors.Is(err, merger.ErrCollectionTerminated) {
+					break paging
+				}
+				return nil, err
+			}
+		}
+		if n < autocompletePage || uint32(ids[n-1]) == ^uint32(0) {
+			break
+		}
+		first = uint32(ids[n-1]) + 1
 	}
-	if int(cnt) == limit && !terminated {
-		return nil, fmt.Errorf("suggesthip: more than %d documents complete %q; the collector wants them all", limit, query)
-	}
+	runtime.KeepAlive(i)
 	if err := mgr.Collect(c); err != nil {
 		return nil, err
 	}
@@ -340,8 +469,10 @@ func (i *Index) Autocomplete(query string, factory suggest.CollectorManagerFacto
 // pkg/lm/binary.go:101-199); NewSpellCheckerFromBinary is BuildSpellChecker's own path (internal/spellchecker/dep/
 // spellchecker.go:13-53): <name>.lm + <name>.cdb through sg_lm_load_binary.
 type SpellChecker struct {
-	lm    *C.sg_lm
-	index *C.sg_index
+	lm     *C.sg_lm
+	index  *C.sg_index
+	mu     sync.RWMutex
+	closed bool
 }
 
 // NewSpellChecker mirrors internal/spellchecker/dep.BuildSpellChecker for a model directory.
@@ -350,25 +481,37 @@ func NewSpellChecker(dir string, order int, startSymbol, endSymbol string, alpha
 	defer C.free(unsafe.Pointer(cdir))
 	defer C.free(unsafe.Pointer(cs))
 	defer C.free(unsafe.Pointer(ce))
-	cstrings := func(xs []string) (**C.char, func()) {
-		arr := (**C.char)(C.malloc(C.size_t(len(xs)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-		sl := unsafe.Slice(arr, len(xs))
-		for i, x := range xs {
-			sl[i] = C.CString(x)
-		}
-		return arr, func() {
-			for _, p := range sl {
-				C.free(unsafe.Pointer(p))
-			}
-			C.free(unsafe.Pointer(arr))
-		}
+	lmAlpha, freeLm := cstrings(alphabet)
+	defer freeLm()
+	sc := &SpellChecker{}
+	if err := ccall(func() C.int {
+		return C.sg_lm_load_google_ex(cdir, C.uint32_t(order), cs, ce, lmAlpha, C.uint32_t(len(alphabet)), 1, &sc.lm)
+	}); err != nil {
+		return nil, err
+	}
+	return sc.finish(d, device)
+}
+
+// NewSpellCheckerFromBinary opens what `lm build-lm` left behind — <name>.lm and <name>.cdb — like
+// lm.RetrieveLMFromBinary (pkg/lm/binary.go:59-98) inside BuildSpellChecker.
+func NewSpellCheckerFromBinary(lmPath, cdbPath, startSymbol, endSymbol string, alphabet []string, d suggest.IndexDescription, device int) (*SpellChecker, error) {
+	cl, cc, cs, ce := C.CString(lmPath), C.CString(cdbPath), C.CString(startSymbol), C.CString(endSymbol)
+	for _, p := range []*C.char{cl, cc, cs, ce} {
+		defer C.free(unsafe.Pointer(p))
 	}
 	lmAlpha, freeLm := cstrings(alphabet)
 	defer freeLm()
 	sc := &SpellChecker{}
-	if rc := C.sg_lm_load_google_ex(cdir, C.uint32_t(order), cs, ce, lmAlpha, C.uint32_t(len(alphabet)), 1, &sc.lm); rc != 0 {
-		return nil, lastError(rc)
+	if err := ccall(func() C.int {
+		return C.sg_lm_load_binary(cl, cc, cs, ce, lmAlpha, C.uint32_t(len(alphabet)), &sc.lm)
+	}); err != nil {
+		return nil, err
 	}
+	return sc.finish(d, device)
+}
+
+// finish builds the fuzzy index over the model's vocabulary (docID = word id) on `device`.
+func (sc *SpellChecker) finish(d suggest.IndexDescription, device int) (*SpellChecker, error) {
 	ixAlpha, freeIx := cstrings(d.Alphabet)
 	defer freeIx()
 	w0, w1, pad := C.CString(d.Wrap[0]), C.CString(d.Wrap[1]), C.CString(d.Pad)
@@ -379,56 +522,25 @@ func NewSpellChecker(dir string, order int, startSymbol, endSymbol string, alpha
 	defer C.free(unsafe.Pointer(desc))
 	desc.ngram_size, desc.wrap_start, desc.wrap_end, desc.pad = C.uint32_t(d.NGramSize), w0, w1, pad
 	desc.alphabet, desc.n_alphabet = ixAlpha, C.uint32_t(len(d.Alphabet))
-	if rc := C.sg_spell_index_build(sc.lm, desc, C.int(device), &sc.index); rc != 0 {
+	if err := ccall(func() C.int { return C.sg_spell_index_build(sc.lm, desc, C.int(device), &sc.index) }); err != nil {
 		C.sg_lm_release(sc.lm)
-		return nil, lastError(rc)
+		return nil, err
 	}
-	runtime.SetFinalizer(sc, func(s *SpellChecker) { C.sg_index_release(s.index); C.sg_lm_release(s.lm) })
+	runtime.SetFinalizer(sc, func(s *SpellChecker) { s.Close() })
 	return sc, nil
 }
 
-// NewSpellCheckerFromBinary opens what `lm build-lm` left behind — <name>.lm and <name>.cdb — like
-// lm.RetrieveLMFromBinary (pkg/lm/binary.go:59-98) inside BuildSpellChecker.
-func NewSpellCheckerFromBinary(lmPath, cdbPath, startSymbol, endSymbol string, alphabet []string, d suggest.IndexDescription, device int) (*SpellChecker, error) {
-	cl, cc, cs, ce := C.CString(lmPath), C.CString(cdbPath), C.CString(startSymbol), C.CString(endSymbol)
-	for _, p := range []*C.char{cl, cc, cs, ce} {
-		defer C.free(unsafe.Pointer(p))
+// Close gives the model and the vocabulary index back (calls in flight hold references of their own).
+func (s *SpellChecker) Close() {
+	s.mu.Lock()
+	defer s.mu.Unlock()
+	if s.closed {
+		return
 	}
-	mk := func(xs []string) (**C.char, func()) {
-		arr := (**C.char)(C.malloc(C.size_t(len(xs)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-		sl := unsafe.Slice(arr, len(xs))
-		for i, x := range xs {
-			sl[i] = C.CString(x)
-		}
-		return arr, func() {
-			for _, p := range sl {
-				C.free(unsafe.Pointer(p))
-			}
-			C.free(unsafe.Pointer(arr))
-		}
-	}
-	lmAlpha, freeLm := mk(alphabet)
-	defer freeLm()
-	sc := &SpellChecker{}
-	if rc := C.sg_lm_load_binary(cl, cc, cs, ce, lmAlpha, C.uint32_t(len(alphabet)), &sc.lm); rc != 0 {
-		return nil, lastError(rc)
-	}
-	ixAlpha, freeIx := mk(d.Alphabet)
-	defer freeIx()
-	w0, w1, pad := C.CString(d.Wrap[0]), C.CString(d.Wrap[1]), C.CString(d.Pad)
-	defer C.free(unsafe.Pointer(w0))
-	defer C.free(unsafe.Pointer(w1))
-	defer C.free(unsafe.Pointer(pad))
-	desc := (*C.sg_desc)(C.malloc(C.size_t(unsafe.Sizeof(C.sg_desc{}))))
-	defer C.free(unsafe.Pointer(desc))
-	desc.ngram_size, desc.wrap_start, desc.wrap_end, desc.pad = C.uint32_t(d.NGramSize), w0, w1, pad
-	desc.alphabet, desc.n_alphabet = ixAlpha, C.uint32_t(len(d.Alphabet))
-	if rc := C.sg_spell_index_build(sc.lm, desc, C.int(device), &sc.index); rc != 0 {
-		C.sg_lm_release(sc.lm)
-		return nil, lastError(rc)
-	}
-	runtime.SetFinalizer(sc, func(s *SpellChecker) { C.sg_index_release(s.index); C.sg_lm_release(s.lm) })
-	return sc, nil
+	s.closed = true
+	C.sg_index_release(s.index)
+	C.sg_lm_release(s.lm)
+	runtime.SetFinalizer(s, nil)
 }
 
 // Predict has the signature of spellchecker.SpellChecker.Predict.
@@ -444,17 +556,29 @@ func (s *SpellChecker) Predict(query string, topK int, similarity float64) ([]st
 	if len(q) > 0 {
 		qp = (*C.uint8_t)(unsafe.Pointer(&q[0]))
 	}
-	if rc := C.sg_spell_predict_batch(s.index, s.lm, qp, &offs[0], 1, C.uint32_t(topK), C.double(similarity), &ids[0], &count); rc != 0 {
-		return nil, lastError(rc)
+	s.mu.RLock() // both handles stay valid while this call is in flight
+	if s.closed {
+		s.mu.RUnlock()
+		return nil, errClosed
+	}
+	C.sg_index_retain(s.index)
+	C.sg_lm_retain(s.lm)
+	s.mu.RUnlock()
+	err := ccall(func() C.int {
+		return C.sg_spell_predict_batch(s.index, s.lm, qp, &offs[0], 1, C.uint32_t(topK), C.double(similarity), &ids[0], &count)
+	})
+	defer func() { C.sg_lm_release(s.lm); C.sg_index_release(s.index); runtime.KeepAlive(s) }()
+	if err != nil {
+		return nil, err
 	}
 	switch uint32(count) {
-	case 0xFFFFFFFF:
+	case C.SG_COUNT_REF_PANIC:
 		panic("makechan: size out of range") // what the reference does (suggester.go:62)
-	case 0xFFFFFFFE:
+	case C.SG_COUNT_REF_DEADLOCK:
 		return nil, fmt.Errorf("suggest_hip: the reference dead-locks on this query (suggester.go:62)")
-	case 0xFFFFFFFD:
-		return nil, fmt.Errorf("suggest_hip: query word has more than 128 n-grams")
-	case 0xFFFFFFFC:
+	case C.SG_COUNT_TOO_LONG:
+		return nil, fmt.Errorf("suggest_hip: query word has more than %d n-grams", int(C.SG_MAX_QUERY_TERMS))
+	case C.SG_COUNT_LM_ERROR:
 		return nil, fmt.Errorf("nGrams length should be less than the nGramModel order") // ngram_model.go:66
 	}
 	out := make([]string, 0, int(count))

@@ -53,10 +53,10 @@ enum sg_error {
  * beyond the device path's limits.  Rows of such queries are left zeroed. */
 #define SG_COUNT_REF_PANIC 0xFFFFFFFFu     /* reference: make(chan, negative) panics */
 #define SG_COUNT_REF_DEADLOCK 0xFFFFFFFEu  /* reference: capacity-0 channel, send blocks forever */
-#define SG_COUNT_TOO_LONG 0xFFFFFFFDu      /* more than SG_MAX_QUERY_TERMS n-grams */
+#define SG_COUNT_TOO_LONG 0xFFFFFFFDu      /* more than SG_MAX_QUERY_TERMS n-grams (queries above 128 n-grams take a slower kernel) */
 #define SG_COUNT_LM_ERROR 0xFFFFFFFCu       /* LanguageModel.Next returned an error (sg_spell_predict_batch) */
-#define SG_MAX_QUERY_TERMS 128u
-#define SG_MAX_TOPK 1024u
+#define SG_MAX_QUERY_TERMS 65536u
+#define SG_MAX_TOPK 65536u
 
 /* suggest.Index + Writer.AddDocument/Commit + Reader.Read
  * (pkg/suggest/indexer.go:14-45, pkg/index/indexer_writer.go:66-145, index_reader.go:29-120):
@@ -66,7 +66,7 @@ int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, c
 
 /* Same index, built on the GPU `device`: documents are tokenised by the kernel-side tokenizer, terms
  * interned in a device hash table, postings radix-sorted and laid out as the same CSR — array for array identical to
- * sg_index_build's (sg_index_digest).  Fails with SG_E_UNSUPPORTED when a document has more than SG_MAX_QUERY_TERMS
+ * sg_index_build's (sg_index_digest).  Fails with SG_E_UNSUPPORTED when a document has more than 128
  * n-grams (use sg_index_build).  The index still has to be uploaded with sg_index_upload. */
 int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device,
                           sg_index** out);
@@ -136,6 +136,14 @@ int sg_suggest_one(sg_index* index, const uint8_t* q_utf8, uint32_t len, int met
                    uint32_t* out_ids, double* out_scores, uint32_t* out_count);
 int sg_autocomplete_one(sg_index* index, const uint8_t* q_utf8, uint32_t len, uint32_t limit, uint32_t* out_ids,
                         uint32_t* out_count);
+/* Autocomplete restricted to documents with docID >= first_doc (the `limit` smallest of those).  The reference hands EVERY
+ * match to the caller's collector (pkg/suggest/autocomplete.go:40-77; pkg/spellchecker/collector.go:61-79 ranks them all):
+ * a binding that must do the same pages through them — first_doc = 0, then the last docID of a page + 1, until a page comes
+ * back with fewer than `limit` entries. */
+int sg_autocomplete_one_from(sg_index* index, const uint8_t* q_utf8, uint32_t len, uint32_t first_doc, uint32_t limit,
+                             uint32_t* out_ids, uint32_t* out_count);
+int sg_autocomplete_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t first_doc,
+                               uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
 
 /* Reference counting: the Go shim retains while a query is in flight and releases from a
  * finalizer, mirroring the reference's mmap release (pkg/index/index_reader.go:49-51). */

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("SG_LIB_NAME", "libsuggest_hip.so"
 SG_COUNT_REF_PANIC = 0xFFFFFFFF
 SG_COUNT_REF_DEADLOCK = 0xFFFFFFFE
 SG_COUNT_TOO_LONG = 0xFFFFFFFD
-SG_MAX_QUERY_TERMS = 128
-SG_MAX_TOPK = 1024
+SG_MAX_QUERY_TERMS = 65536
+SG_MAX_TOPK = 65536
 
 EXPORTS = [
     "sg_index_build", "sg_index_build_device", "sg_index_build_ex", "sg_index_digest", "sg_index_load_reference", "sg_index_upload", "sg_suggest_batch", "sg_suggest_batch_device", "sg_autocomplete_batch",
@@ -22,7 +22,7 @@ EXPORTS = [
     "sg_tokenize", "sg_term_string", "sg_index_list", "sg_index_lists", "sg_suggest_algorithmic_bytes",
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch", "sg_spell_predict_batch_device",
-    "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one",
+    "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one", "sg_autocomplete_one_from", "sg_autocomplete_batch_from",
     "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
@@ -76,6 +76,8 @@ def lib():
     if hasattr(L, "sg_autocomplete_one"): L.sg_autocomplete_one.argtypes = [vp, C.c_char_p, u32, u32, vp, vp]
     if hasattr(L, "sg_suggest_batch_device"): L.sg_suggest_batch_device.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, vp]
     if hasattr(L, "sg_autocomplete_batch"): L.sg_autocomplete_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    if hasattr(L, "sg_autocomplete_batch_from"): L.sg_autocomplete_batch_from.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp]
+    if hasattr(L, "sg_autocomplete_one_from"): L.sg_autocomplete_one_from.argtypes = [vp, C.c_char_p, u32, u32, u32, vp, vp]
     if hasattr(L, "sg_autocomplete_batch_device"): L.sg_autocomplete_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     if hasattr(L, "sg_lm_load_google"): L.sg_lm_load_google.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
     if hasattr(L, "sg_lm_load_google_ex"): L.sg_lm_load_google_ex.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp)]

@@ -149,6 +149,11 @@ struct BatchArgs {
   // a launch over a subset of the batch (the spellchecker's fuzzy top-up): workgroup b runs query q_sel[b], b < *q_sel_n
   const uint32_t* q_sel;
   const uint32_t* q_sel_n;
+  // ---- queries beyond the wavefront kernel's tables (more than SG_MAX_A n-grams): sg_long_kernel, HBM working memory ----
+  uint8_t* long_scratch;  // [SG_LONG_SLOTS] slots of long_slot_bytes; null: such queries are flagged SG_COUNT_TOO_LONG
+  uint32_t* long_lock;    // [SG_LONG_SLOTS] 0 free / 1 taken (launches on several streams share the replica's slots)
+  uint64_t long_slot_bytes;
+  uint32_t long_max_seg;  // documents of the largest cardinality segment (the slot's counter array)
   uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative, one query in 32
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
@@ -187,7 +192,7 @@ __device__ int d_max_y(int m, double alpha, int size, int cap) {  // result clam
 __device__ int d_threshold(int m, double alpha, int a, int b) {
   switch (m) {
     case SG_JACCARD: return (int)ceil(alpha * (double)(a + b) / (1 + alpha));
-    case SG_COSINE: return (int)ceil(alpha * sqrt((double)(a * b)));
+    case SG_COSINE: return (int)ceil(alpha * sqrt((double)((long long)a * (long long)b)));   // (Go's int is 64 bits wide)
     case SG_DICE: return (int)ceil(0.5 * alpha * (double)(a + b));
     case SG_EXACT: return a;
     default: return (int)ceil(alpha * fmin((double)a, (double)b));
@@ -197,7 +202,7 @@ __device__ double d_score(int m, int inter, int a, int b) {  // 1 - Distance(...
   double dist;
   switch (m) {
     case SG_JACCARD: dist = 1 - (double)inter / (double)(a + b - inter); break;
-    case SG_COSINE: dist = 1 - (double)inter / sqrt((double)(a * b)); break;
+    case SG_COSINE: dist = 1 - (double)inter / sqrt((double)((long long)a * (long long)b)); break;
     case SG_DICE: dist = 1 - (double)(2 * inter) / (double)(a + b); break;
     case SG_EXACT: dist = 0; break;
     default: dist = 1 - (double)inter / fmin((double)a, (double)b); break;
@@ -1669,6 +1674,318 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Queries beyond the wavefront kernel's tables (more than SG_MAX_A n-grams / SG_MAX_RUNES runes).  The reference has no
+// such limit (pkg/suggest/suggester.go:46-59); the wavefront kernel marks these queries SG_COUNT_TOO_LONG and this
+// kernel, launched behind it, answers them — exactly, on the device, with its working memory in HBM instead of LDS:
+//   tokenise (any length up to SG_LONG_MAX_TERMS n-grams; appendUnique through a hash of first positions)
+//   -> per admissible segment: zero one counter per document of the segment, add 1 per posting of every query-term
+//      occurrence (ScanCount, pkg/merger/scan_count.go:14-88 — the same result set as CPMerge), collect counts >= T
+//   -> score, top-k, the secondary entries of documents that repeat a term — as the wavefront kernel does.
+// A few workgroups of one wavefront; each takes a slot of the replica's long-query scratch when it meets a marked query
+// (launches on several streams share the slots: a lock word per slot).  Speed is beside the point here — such queries are
+// rare — but nothing is approximated and nothing goes to the host.
+// ------------------------------------------------------------------------------------------
+#define SG_LONG_SLOTS 4
+#define SG_LONG_MAX_TERMS 65536u
+#define SG_LONG_MAX_RUNES (SG_LONG_MAX_TERMS + 2u * SG_WRAP_MAX + 8u)
+#define SG_LONG_HASH (2u * SG_LONG_MAX_TERMS)
+struct LongSlot {   // offsets (bytes) into a slot
+  static constexpr uint64_t o_runes = 0;
+  static constexpr uint64_t o_keys = o_runes + 4ull * SG_LONG_MAX_RUNES + 32;
+  static constexpr uint64_t o_term = o_keys + 8ull * SG_LONG_MAX_TERMS;
+  static constexpr uint64_t o_hash = o_term + 4ull * SG_LONG_MAX_TERMS;
+  static constexpr uint64_t o_sk = o_hash + 4ull * SG_LONG_HASH;
+  static constexpr uint64_t o_sv = o_sk + 4ull * SG_LONG_MAX_TERMS;
+  static constexpr uint64_t o_stk = o_sv + 4ull * SG_LONG_MAX_TERMS;
+  static constexpr uint64_t o_extra = o_stk + 4ull * 512;
+  static constexpr uint64_t o_tks = o_extra + 4ull * 64;
+  static constexpr uint64_t o_tkid = o_tks + 8ull * SG_K_LDS;
+  static constexpr uint64_t o_cnt = o_tkid + 4ull * SG_K_LDS + 64;     // [long_max_seg] one counter per document of a segment
+  static uint64_t bytes(uint32_t max_seg) { return (o_cnt + 4ull * ((uint64_t)max_seg + 64) + 255) & ~255ull; }
+};
+template <class T> __device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // past the L1: the word may have been changed by an atomic
+
+__device__ __forceinline__ bool long_same_gram(const uint32_t* runes, uint32_t g1, uint32_t g2, uint32_t q_n) {
+  bool eq = true;
+  for (uint32_t t = 0; t < q_n; t++) eq &= runes[g1 + t] == runes[g2 + t];
+  return eq;
+}
+__device__ __forceinline__ uint32_t long_gram_hash(const uint32_t* runes, uint32_t g, uint32_t q_n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  for (uint32_t t = 0; t < q_n; t++) h = d_mix64(h ^ (uint64_t)runes[g + t]);
+  return (uint32_t)h;
+}
+
+__device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int lane) {
+  const DeviceIndex& ix = a.ix;
+  uint32_t* runes = (uint32_t*)(slot + LongSlot::o_runes);
+  uint64_t* keys = (uint64_t*)(slot + LongSlot::o_keys);
+  uint32_t* term = (uint32_t*)(slot + LongSlot::o_term);
+  uint32_t* htab = (uint32_t*)(slot + LongSlot::o_hash);
+  uint32_t* sk = (uint32_t*)(slot + LongSlot::o_sk);
+  uint32_t* sv = (uint32_t*)(slot + LongSlot::o_sv);
+  int* stk = (int*)(slot + LongSlot::o_stk);
+  uint32_t* extra = (uint32_t*)(slot + LongSlot::o_extra);
+  uint32_t* cnt = (uint32_t*)(slot + LongSlot::o_cnt);
+  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
+  const uint8_t* q = a.q_blob + qb;
+  const uint64_t qlen64 = qe - qb;
+  if (qlen64 > SG_LONG_MAX_TERMS) return;                       // stays SG_COUNT_TOO_LONG
+  const uint32_t qlen = (uint32_t)qlen64, k = a.k;
+  // ---- wrap -> lower -> runes (the same uniform sequential decode as the wavefront kernel's rare path; ASCII in parallel) ----
+  const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete ? 0u : ix.n_wrap1;
+  bool na = false;
+  for (uint32_t i = lane; i < qlen; i += 64) na |= q[i] >= 0x80;
+  uint32_t R = 0, byte_len = 0;
+  if (!ballot(na)) {
+    R = n_w0 + qlen + n_w1;
+    for (uint32_t i = lane; i < qlen; i += 64) { const uint32_t b = q[i]; runes[n_w0 + i] = (b - 'A' < 26u) ? b + 32u : b; }
+    if ((uint32_t)lane < n_w0) runes[lane] = d_lower(ix, ix.wrap0[lane]);
+    if ((uint32_t)lane < n_w1) runes[n_w0 + qlen + lane] = d_lower(ix, ix.wrap1[lane]);
+    byte_len = qlen;
+    for (uint32_t i = 0; i < n_w0; i++) byte_len += d_width(d_lower(ix, ix.wrap0[i]));
+    for (uint32_t i = 0; i < n_w1; i++) byte_len += d_width(d_lower(ix, ix.wrap1[i]));
+  } else {
+    for (uint32_t i = 0; i < n_w0; i++) { const uint32_t r = d_lower(ix, ix.wrap0[i]); if (lane == 0) runes[R] = r; R++; byte_len += d_width(r); }
+    for (uint32_t i = 0; i < qlen;) {
+      uint32_t adv;
+      const uint32_t r = d_lower(ix, d_next_rune(q + i, qlen - i, &adv));
+      i += adv;
+      if (lane == 0) runes[R] = r;
+      R++; byte_len += d_width(r);
+    }
+    for (uint32_t j = 0; j < n_w1; j++) { const uint32_t r = d_lower(ix, ix.wrap1[j]); if (lane == 0) runes[R] = r; R++; byte_len += d_width(r); }
+  }
+  __syncthreads();
+  uint32_t t0 = 0, t1 = R;                                      // strings.Trim(text, " ")
+  while (t0 < t1 && runes[t0] == ' ') { t0++; byte_len--; }
+  while (t1 > t0 && runes[t1 - 1] == ' ') { t1--; byte_len--; }
+  const uint32_t q_n = ix.q;
+  uint32_t A = 0;
+  if (byte_len < q_n) A = 0;                                    // ngram_tokenizer.go:18
+  else if (t1 - t0 <= q_n) {                                    // one short gram: the whole text
+    if (lane == 0) { uint32_t w[8]; for (uint32_t t = 0; t < t1 - t0; t++) w[t] = runes[t0 + t]; keys[0] = d_pack_key(ix, w, t1 - t0); }
+    A = 1;
+  } else {
+    // appendUnique (ngram_tokenizer.go:46-54): a gram stays where it FIRST occurs.  htab: the smallest position of every
+    // distinct gram (open addressing on the runes of the window; equal windows meet in one slot and keep the minimum).
+    const uint32_t G = t1 - t0 - q_n + 1;
+    uint32_t H = 64;
+    while (H < 2u * G) H <<= 1;
+    for (uint32_t i = lane; i < H; i += 64) htab[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t g = lane; g < G; g += 64) {
+      for (uint32_t h = long_gram_hash(runes, t0 + g, q_n) & (H - 1u);; h = (h + 1u) & (H - 1u)) {
+        uint32_t cur = ld_l2(htab + h);
+        if (cur == 0xFFFFFFFFu) { cur = atomicCAS(htab + h, 0xFFFFFFFFu, g); if (cur == 0xFFFFFFFFu) break; }
+        if (long_same_gram(runes, t0 + cur, t0 + g, q_n)) { atomicMin(htab + h, g); break; }
+      }
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < G; base += 64) {
+      const uint32_t g = base + (uint32_t)lane;
+      bool keep = false;
+      if (g < G)
+        for (uint32_t h = long_gram_hash(runes, t0 + g, q_n) & (H - 1u);; h = (h + 1u) & (H - 1u)) {
+          const uint32_t cur = ld_l2(htab + h);
+          if (long_same_gram(runes, t0 + cur, t0 + g, q_n)) { keep = cur == g; break; }
+        }
+      const uint64_t m = ballot(keep);
+      if (keep) {
+        uint32_t w[8];
+        for (uint32_t t = 0; t < q_n; t++) w[t] = runes[t0 + g + t];
+        keys[A + popc64(m & ((1ull << lane) - 1ull))] = d_pack_key(ix, w, q_n);
+      }
+      A += popc64(m);
+    }
+  }
+  __syncthreads();
+  if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
+  if (ix.slots) for (uint32_t i = lane; i < A; i += 64) term[i] = d_term_lookup(ix, keys[i]);
+  __syncthreads();
+  // ---- window (suggester.go:53-62) ----
+  const int S = (int)ix.S;
+  int b_min, b_max;
+  if (a.autocomplete) { b_min = (int)A; b_max = S - 1; }
+  else {
+    b_min = d_min_y(a.metric, a.alpha, (int)A);
+    b_max = d_max_y(a.metric, a.alpha, (int)A, S);
+    if (b_max >= S) b_max = S - 1;
+    const int span = b_max - b_min + 1;
+    if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; return; }
+    if (span == 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_DEADLOCK; return; }
+  }
+  b_min = max(b_min, 0);
+  TopK tk;
+  tk.s = k <= SG_K_LDS ? (uint64_t*)(slot + LongSlot::o_tks) : a.scratch_s + (uint64_t)qi * k;
+  tk.id = k <= SG_K_LDS ? (uint32_t*)(slot + LongSlot::o_tkid) : a.scratch_id + (uint64_t)qi * k;
+  tk.n = 0; tk.k = k; tk.worst_s = 0; tk.worst_id = 0; tk.worst_pos = 0;
+  const uint32_t lm_from = a.lm_values ? a.lm_from[qi] : 0u, lm_to = a.lm_values ? a.lm_to[qi] : 0u;
+  const uint32_t S1 = (uint32_t)S + 1u;
+  for (int B = b_min; B <= b_max; B++) {
+    int T = (int)A;
+    if (!a.autocomplete) {
+      T = d_threshold(a.metric, a.alpha, (int)A, B);
+      if (T == 0 || T > B || T > (int)A) continue;               // suggester.go:76
+    }
+    const uint32_t x0 = ix.seg_base[B], n_seg = ix.seg_base[B + 1] - x0;
+    if (n_seg == 0u || n_seg > a.long_max_seg) continue;
+    uint32_t ne = 0;                                            // searcher.go:32: fewer present terms than T
+    for (uint32_t i = lane; i < A; i += 64) { const uint32_t t = term[i]; if (t != kNoTerm) ne += ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u] != ix.seg_off[(uint64_t)t * S1 + (uint32_t)B]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ne += (uint32_t)__shfl_xor((int)ne, off, 64);
+    if ((int)ne < T) continue;
+    for (uint32_t j = lane; j < n_seg; j += 64) cnt[j] = 0u;
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = 0; i < A; i++) {                           // one posting list per query-term OCCURRENCE
+      const uint32_t t = term[i];
+      if (t == kNoTerm) continue;
+      const uint32_t c0 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], c1 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u];
+      for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += 64) {
+        u32x8v pc;
+        decode_chunk(((const uint4*)ix.postings)[c], pc, 0);
+#pragma unroll
+        for (int e = 0; e < SG_PPC; e++) if (e == 0 || pc[e] != pc[e - 1]) atomicAdd(cnt + (pc[e] - x0), 1u);
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < n_seg; j0 += 64) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const uint32_t c = j < n_seg ? ld_l2(cnt + j) : 0u;
+      uint64_t m = ballot(c >= (uint32_t)T);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t x = x0 + j0 + (uint32_t)l, ov = readlane(c, l);
+        const uint32_t d = __builtin_amdgcn_readfirstlane(ix.orig_of[x]);
+        auto offer = [&](int overlap) {
+          if (a.lm_values) topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
+          else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }
+          else topk_insert(tk, score_bits(d_score(a.metric, overlap, (int)A, B)), d, lane);
+        };
+        offer((int)ov);
+        if (ix.n_dup_docs && ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u)) {
+          // the secondary entries of a document that repeats a term — dup_secondary_overlaps, with the
+          // per-list view taken from the store and the tables in HBM
+          __syncthreads();
+          uint32_t n = 0;
+          for (uint32_t base = 0; base < A; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            bool present = false;
+            uint32_t len = 0, mult = 0;
+            if (i < A && term[i] != kNoTerm) {
+              const uint32_t t = term[i];
+              const uint32_t c0 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], nch = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u] - c0;
+              present = nch != 0u;
+              if (present) {
+                bool has = false;
+                {
+                  const uint32_t* p = ix.postings + (uint64_t)c0 * 4;
+                  uint32_t lo = 0, hi = nch;
+                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[(uint64_t)mid * 4] <= x) lo = mid + 1; else hi = mid; }
+                  if (lo) { u32x8v pc; decode_chunk(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC; e++) has |= pc[e] == x; }
+                }
+                const uint32_t ts = t * (uint32_t)S + (uint32_t)B;
+                len = ix.list_len[ts];
+                const uint32_t eix = d_lower_bound_u32(ix.extra_ts, ix.n_extra, ts);
+                const uint32_t raw = len + ((eix < ix.n_extra && ix.extra_ts[eix] == ts) ? ix.extra_cnt[eix] : 0u);
+                mult = has ? 1u : 0u;
+                if (raw <= 256u) {
+                  len = raw;
+                  if (has) {
+                    uint32_t lo = d_lower_bound_u32(ix.dup_ts, ix.n_dups, ts);
+                    while (lo < ix.n_dups && ix.dup_ts[lo] == ts && ix.dup_doc[lo] < d) lo++;
+                    if (lo < ix.n_dups && ix.dup_ts[lo] == ts && ix.dup_doc[lo] == d) mult = ix.dup_mult[lo];
+                  }
+                }
+              }
+            }
+            const uint64_t pm = ballot(present);
+            if (present) { const uint32_t pos = n + popc64(pm & ((1ull << lane) - 1ull)); sk[pos] = len; sv[pos] = mult; }
+            n += popc64(pm);
+          }
+          __threadfence();
+          __syncthreads();
+          PairSort ps{sk, sv, stk};
+          ps.sort((int)n);
+          __threadfence();
+          __syncthreads();
+          const int T0 = a.autocomplete ? (int)A : d_threshold(a.metric, a.alpha, (int)A, B);
+          int n_extra = 0;
+          if ((int)n == T0) {
+            const int copies = (int)sv[0];
+            for (int c2 = 1; c2 < copies && n_extra < 64; c2++) { if (lane == 0) extra[n_extra] = n; n_extra++; }
+          } else if ((int)n > T0) {
+            const int min_q = (int)n - T0 + 1;
+            uint32_t maxm = 0;
+            int tail = 0;
+            for (int pp = 0; pp < (int)n; pp++) { if (pp < min_q) maxm = max(maxm, sv[pp]); else tail += sv[pp] ? 1 : 0; }
+            for (uint32_t jj = 2; jj <= maxm && n_extra < 64; jj++) {
+              int c2 = tail;
+              for (int pp = 0; pp < min_q; pp++) c2 += sv[pp] >= jj ? 1 : 0;
+              if (c2 >= T0) { if (lane == 0) extra[n_extra] = (uint32_t)c2; n_extra++; }
+            }
+          }
+          __threadfence();
+          __syncthreads();
+          for (int e2 = 0; e2 < n_extra; e2++) offer((int)extra[e2]);
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- GetCandidates (topk.go:127-147): best first ----
+  __syncthreads();
+  uint32_t* out_ids = a.out_ids + (uint64_t)qi * k;
+  double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
+  const uint32_t n = tk.n;
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint64_t s = tk.s[i];
+    const uint32_t d = tk.id[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      const uint64_t sj = tk.s[j];
+      const uint32_t dj = tk.id[j];
+      rank += (better(sj, dj, s, d) || (sj == s && dj == d && j < i)) ? 1u : 0u;
+    }
+    out_ids[rank] = d;
+    if (out_scores) out_scores[rank] = bits_score(s);
+  }
+  if (lane == 0) a.out_counts[qi] = n;
+}
+
+__global__ __launch_bounds__(64) void sg_long_kernel(const BatchArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t n_work = a.q_sel ? __builtin_amdgcn_readfirstlane(*a.q_sel_n) : a.n_q;
+  int slot = -1;
+  for (uint32_t b = blockIdx.x; b < n_work; b += gridDim.x) {
+    const uint32_t qi = a.q_sel ? __builtin_amdgcn_readfirstlane(a.q_sel[b]) : b;
+    if (__builtin_amdgcn_readfirstlane(a.out_counts[qi]) != SG_COUNT_TOO_LONG) continue;
+    if (slot < 0) {                                              // a slot of the replica's long-query scratch
+      if (lane == 0) {
+        for (int sidx = (int)(blockIdx.x % SG_LONG_SLOTS);; sidx = (sidx + 1) % SG_LONG_SLOTS) {
+          if (atomicCAS(a.long_lock + sidx, 0u, 1u) == 0u) { slot = sidx; break; }
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      __threadfence();
+      __syncthreads();
+    }
+    long_query(a, qi, a.long_scratch + (uint64_t)slot * a.long_slot_bytes, lane);
+    __syncthreads();
+  }
+  if (slot >= 0) {
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(a.long_lock + slot, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // SpellChecker.Predict on the device (pkg/spellchecker/spellchecker.go:40-92), the steps around the two searches:

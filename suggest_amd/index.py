@@ -191,6 +191,24 @@ class NGramIndex:
                 h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, int(limit), ids.ctypes.data, cnt.ctypes.data))
         return ids, cnt
 
+    def autocomplete_all(self, query, page=1024):
+        """EVERY document the prefix completes, ascending docID — what the reference's Autocomplete hands to the caller's
+        collector (pkg/suggest/autocomplete.go:40-77) — paged through sg_autocomplete_one_from."""
+        q = _enc(query)
+        out, first = [], 0
+        ids = np.zeros(page, dtype=np.uint32)
+        cnt = C.c_uint32()
+        while True:
+            with self._use() as h:
+                _lib.check(_lib.lib().sg_autocomplete_one_from(h, q, len(q), int(first), int(page), ids.ctypes.data, C.addressof(cnt)))
+            c = int(cnt.value)
+            if c >= _lib.SG_COUNT_LM_ERROR:
+                raise ValueError("query cannot be answered (status %#x)" % c)
+            out.extend(int(x) for x in ids[:min(c, page)])
+            if c < page or out[-1] == 0xFFFFFFFF:
+                return out
+            first = out[-1] + 1
+
     # ---- search: device-resident buffers (raw pointers; torch tensors' data_ptr()) ---------
     def suggest_batch_device(self, d_blob, d_offs, n_q, metric, similarity, k, d_ids, d_scores, d_counts, stream=0):
         with self._use() as h:

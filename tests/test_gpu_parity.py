@@ -454,8 +454,8 @@ def test_doc_sharded_index_merges_to_the_unsharded_result():
 
 
 def test_limits_long_ngrams_max_k_and_query_length():
-    """The edges of the device path: n-grams of 5 and 8 runes (the 64-bit term key is full at 8), k = SG_MAX_TOPK,
-    queries with exactly SG_MAX_QUERY_TERMS n-grams (answered) and one more (flagged, never answered wrongly)."""
+    """The edges of the wavefront kernel: n-grams of 5 and 8 runes (the 64-bit term key is full at 8), k = 1024 and beyond
+    (top-k rows in HBM), queries with exactly 128 n-grams (its last) and one more (the first the long-query kernel takes)."""
     import random
     from suggest_amd import NGramIndex, IndexDescription, _lib
     rng = random.Random(77)
@@ -466,10 +466,10 @@ def test_limits_long_ngrams_max_k_and_query_length():
         ora = oracle.OracleIndex(words, **desc)
         queries = [w[:-1] + "x" for w in words[::30]] + words[:40] + ["abc", "a" * q, "a" * (q - 1)]
         qb, qo = oracle.pack_strings(queries)
-        for metric, a, k in (("jaccard", 0.3, 10), ("cosine", 0.5, 1024), ("dice", 0.2, 300)):
+        for metric, a, k in (("jaccard", 0.3, 10), ("cosine", 0.5, 1024), ("dice", 0.2, 300), ("cosine", 0.2, 2500)):
             assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k), ora.suggest_batch(qb, qo, metric, a, k), queries)
     with pytest.raises(Exception):
-        gpu.suggest_batch(queries[:1], metric="jaccard", similarity=0.5, k=1025)
+        gpu.suggest_batch(queries[:1], metric="jaccard", similarity=0.5, k=_lib.SG_MAX_TOPK + 1)
     # query length: q = 3, wrap "$".."$": a string of L distinct-trigram runes has L n-grams
     desc = dict(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "numbers", "$"))
     base = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(rng.randint(100, 140))) for _ in range(300)]
@@ -478,12 +478,59 @@ def test_limits_long_ngrams_max_k_and_query_length():
     exact = [d for d in base if len(ora.tokenize(d)) == 128][:5] or [base[0][:128]]
     over = [d for d in base if len(ora.tokenize(d)) == 129][:5] or [base[0] + b"zq7"]
     qb, qo = oracle.pack_strings(exact + over)
-    ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=5)
-    oi, os_, oc, _ = ora.suggest_batch(qb, qo, "jaccard", 0.5, 5)
-    n_ok = len(exact)
     assert all(len(ora.tokenize(q)) <= 128 for q in exact) and all(len(ora.tokenize(q)) > 128 for q in over)
-    assert_same((ids[:n_ok], sc[:n_ok], cnt[:n_ok]), (oi[:n_ok], os_[:n_ok], oc[:n_ok]))
-    assert (cnt[n_ok:] == _lib.SG_COUNT_TOO_LONG).all()
+    got = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=5)
+    assert_same(got, ora.suggest_batch(qb, qo, "jaccard", 0.5, 5), exact + over)
+    assert (got[2] >= 1).all()                                   # every one of them is in the dictionary
+
+
+def test_long_queries_are_answered_on_the_device():
+    """Queries with more than 128 n-grams (the wavefront kernel's tables): the reference has no such limit
+    (pkg/suggest/suggester.go:46-59) — sg_long_kernel answers them with HBM working memory: ScanCount per segment, the
+    same tokeniser rules (first-occurrence dedup over thousands of grams, non-ASCII runes, wrap), the secondary entries of
+    documents that repeat a term, autocomplete, k above the LDS rows, mixed into a batch of ordinary queries."""
+    import random
+    from suggest_amd import NGramIndex, IndexDescription
+    rng = random.Random(5)
+    alpha = "abcdefghijklmnopqrstuvwxyz0123456789 "
+    desc = dict(ngram_size=3, wrap=("$", "$"), pad="$", alphabet=("english", "russian", "numbers", "$"))
+
+    def text(n, pool=alpha):
+        return "".join(rng.choice(pool) for _ in range(n))
+
+    docs = [text(rng.randint(5, 40)) for _ in range(400)]
+    docs += [text(rng.randint(150, 900)) for _ in range(250)]                       # long documents (host builder)
+    docs += [text(rng.randint(200, 500), "ab ") for _ in range(60)]                  # ... that repeat their terms over and over
+    docs += [text(rng.randint(150, 400), "абвгдежз abc") for _ in range(60)]          # ... with non-ASCII runes
+    docs += [docs[410] + "x", docs[410][:-3], docs[420][5:] + "tail"]
+    gpu = NGramIndex(docs, IndexDescription(**desc))
+    ora = oracle.OracleIndex(docs, **desc)
+
+    def edit(s):
+        s = list(s)
+        for _ in range(rng.randint(1, 6)):
+            s[rng.randrange(len(s))] = rng.choice(alpha)
+        return "".join(s)
+
+    queries = [edit(d) for d in docs[400:] if len(d) > 130][::3] + docs[400:420] + [edit(d) for d in docs[:30]]
+    queries += [text(3000), docs[405] * 3, "ab " * 700, "б" * 300 + docs[715][:200], "x" * 200]
+    queries = [q.encode("utf-8") for q in queries]
+    queries += [b"\xff\xfe" + docs[430].encode("utf-8"), docs[431][:140].encode("utf-8") + b"\xe2\x82" * 40 + "\u20ac".encode("utf-8") * 20]   # invalid UTF-8
+    n_long = sum(1 for q in queries if len(ora.tokenize(q)) > 128)
+    assert n_long > 50
+    qb, qo = oracle.pack_strings(queries)
+    for metric, a, k in (("jaccard", 0.5, 5), ("cosine", 0.3, 10), ("dice", 0.4, 100), ("overlap", 0.6, 7), ("cosine", 0.2, 70)):
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k), ora.suggest_batch(qb, qo, metric, a, k), queries)
+    # autocomplete: every n-gram of the prefix must be in the document
+    prefixes = [d[:rng.randint(130, 200)] for d in docs[400:460] if len(d) > 210] + [docs[10][:4], docs[405][:131]]
+    pb, po = oracle.pack_strings(prefixes)
+    for limit in (3, 80):
+        g_ids, g_cnt = gpu.autocomplete_batch(blob=pb, offs=po, limit=limit)
+        o_ids, o_cnt = ora.autocomplete_batch(pb, po, limit)[:2]
+        assert np.array_equal(g_cnt, o_cnt)
+        valid = np.arange(limit)[None, :] < np.minimum(o_cnt, limit)[:, None]
+        assert np.array_equal(g_ids[valid], o_ids[valid])
+    assert int(g_cnt.sum()) >= len(prefixes) - 2
 
 
 @pytest.mark.parametrize("seed", [300004, 700812])
@@ -498,3 +545,23 @@ def test_fuzz_regressions(seed, monkeypatch):
     for name, value in t["env"].items():
         monkeypatch.setenv(name, value)
     assert fz.run_trial(t) == []
+
+
+def test_autocomplete_pages_through_every_match(golden_dir):
+    """The reference's Autocomplete streams EVERY match to the caller's collector (pkg/suggest/autocomplete.go:40-77); a
+    binding gets them all by paging (sg_autocomplete_one_from: the `limit` smallest docIDs >= first_doc)."""
+    import lzma
+    from conftest import WORDS_DESC
+    from suggest_amd import NGramIndex, IndexDescription
+    words = lzma.open(os.path.join(golden_dir, "words.dict.xz")).read().splitlines()[:60000]
+    gpu = NGramIndex(words, IndexDescription(**WORDS_DESC))
+    ora = oracle.OracleIndex(words, **WORDS_DESC)
+    for prefix in (b"a", b"un", b"pre", b"zzq", b"inter"):
+        qb, qo = oracle.pack_strings([prefix])
+        o_ids, o_cnt = ora.autocomplete_batch(qb, qo, len(words))[:2]
+        want = o_ids[0, :int(o_cnt[0])].tolist()
+        for page in (7, 1000):
+            if len(want) / page > 400:
+                continue
+            assert gpu.autocomplete_all(prefix, page=page) == want
+    assert len(ora.autocomplete_batch(*oracle.pack_strings([b"a"]), len(words))[0]) > 0

@@ -218,3 +218,22 @@ def test_lowercase_tables_of_oracle_and_product_come_from_two_sources_and_agree(
     assert tabs[0] == tabs[1] and len(tabs[0]) == 1364
     assert tabs[0][0x130] == 0x69 and tabs[0][0x410] == 0x430
     assert not any(c in tabs[0] for c in (0xA7C7, 0xA7C9, 0xA7F5, 0x2C2F, 0xA7C0, 0x10570))
+
+
+def test_go_sort_hand_traced_small_inputs(reference_tests):
+    """Go 1.14 sort.Sort on <= 12 elements is two straight-line steps (a ShellSort pass with gap 6, then insertionSort:
+    src/sort/sort.go, quickSort) — traced compare by compare in tests/golden/go_sort_small_traces.txt by a script that
+    implements nothing else (tools/gosort_hand_traces.py).  Both CPU restatements of the full algorithm must give these
+    permutations; the device's PairSort is held to them in the GPU suite.  (The branches above 12 elements — ninther
+    pivot, heapSort fallback — stay pinned only by the three restatements agreeing: no Go toolchain)"""
+    import numpy as np
+    import gosort
+    vectors = reference_tests["go_sort_small"]["vectors"]
+    assert len(vectors) >= 20
+    unstable = 0
+    for v in vectors:
+        keys = np.array(v["keys"], dtype=np.uint32)
+        assert oracle.go_sort(keys) == v["perm"], v
+        assert gosort.go_sort(v["keys"]) == v["perm"], v
+        unstable += v["perm"] != sorted(range(len(keys)), key=lambda i: (v["keys"][i], i))
+    assert unstable >= 3                    # the vectors do show the instability (a stable sort would fail them)
