@@ -153,6 +153,7 @@ struct BatchArgs {
   uint8_t* long_scratch;  // [SG_LONG_SLOTS] slots of long_slot_bytes; null: such queries are flagged SG_COUNT_TOO_LONG
   uint32_t* long_lock;    // [SG_LONG_SLOTS] 0 free / 1 taken (launches on several streams share the replica's slots)
   uint64_t long_slot_bytes;
+  uint32_t* long_list;    // [1 + n_q] the wavefront kernel's list of such queries: [0] = how many (zeroed per launch), then their indices
   uint32_t long_max_seg;  // documents of the largest cardinality segment (the slot's counter array)
   uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative, one query in 32
@@ -897,7 +898,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
   PH(0)
   if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; break; }
-  if (A < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; break; }
+  if (A < 0) {                                                 // beyond this kernel's tables: flagged, and listed for sg_long_kernel
+    if (lane == 0) {
+      a.out_counts[qi] = SG_COUNT_TOO_LONG;
+      if (a.long_list) a.long_list[1u + atomicAdd(a.long_list, 1u)] = qi;
+    }
+    break;
+  }
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; break; }
   auto build_qhash = [&]() {
     for (uint32_t i = lane; i < L::qh; i += 64) qh_key[i] = kNoTerm;
@@ -943,11 +950,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const uint32_t stride = (uint32_t)Wt + 1;
     // ---- chunk offsets of every query term for segments tb .. tb+Wt (searcher.go:38-58) ----
     __syncthreads();
+    // (e / stride by a 20-bit reciprocal: exact for e * stride < 2^20 — e < 128 * 65 — and two full-rate instructions
+    //  where the compiler's unsigned division is twenty)
+    const uint32_t rcp = (1u << 20) / stride + 1u;
     for (uint32_t e = lane; e < (uint32_t)A * stride; e += 64) {
-      const uint32_t i = e / stride, w = e - i * stride;
+      const uint32_t i = __umul24(e, rcp) >> 20, w = e - __umul24(i, stride);
       const uint32_t t = term[i];
       rows[e] = t == kNoTerm ? 0u : ix.seg_off[(uint64_t)t * (uint32_t)(S + 1) + (uint32_t)tb + w];
     }
+    cnt[lane] = 0u; cnt[64 + lane] = 0u;                          // (the counters are idle between groups: scratch of the statistics)
+    __syncthreads();
+    // ---- posting volume and present terms per segment: every lane takes (term, segment) pairs — all 64 lanes busy — and
+    //      adds into the segment's two words; lane w then owns segment tb+w ----
+    for (uint32_t e = lane; e < (uint32_t)A * stride; e += 64) {
+      const uint32_t i = __umul24(e, rcp) >> 20, w = e - __umul24(i, stride);
+      if (w < (uint32_t)Wt) {
+        const uint32_t len = rows[e + 1] - rows[e];
+        if (len) { atomicAdd(cnt + w, len); atomicAdd(cnt + 64 + w, 1u); }
+      }
+    }
+    __syncthreads();
+    const uint32_t seg_vol = cnt[lane], seg_ne = cnt[64 + lane];
     __syncthreads();
     // ---- lane w owns segment tb+w: posting volume, present terms, threshold.  kTight: computed again (for the segments
     //      still to come, w >= w_start) whenever the k-th best score has moved: the thresholds tighten with it. ----
@@ -959,11 +982,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int seg_T = 0;
     bool seg_valid = false;
     if (lane < Wt) {
-      uint32_t ne = 0;
-      for (int i = 0; i < A; i++) {
-        const uint32_t len = rows[i * stride + lane + 1] - rows[i * stride + lane];
-        seg_tot += len; ne += len != 0;
-      }
+      const uint32_t ne = seg_ne;
+      seg_tot = seg_vol;
       const int B = tb + lane;
       if (a.autocomplete) { seg_T = A; seg_valid = true; }
       else {
@@ -1204,15 +1224,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
       }
       __syncthreads();
+      if (DBG_SKIP(2048u | 4096u)) {
 #pragma nounroll
-      for (uint32_t c = 0; c < n; c++) {
-        const uint32_t v = qj[c];
-        DBG_COUNT(7, 1)
-        if (DBG_SKIP(4096u)) { topk_insert(tk, score_bits((double)(v & 0xFFu) + (double)c / 1000.0 + (double)n / 1e6 + (v >> 31 ? 0.5 : 0.0)), qd[c], lane); continue; }
-        if (!(v >> 31)) continue;
-        DBG_COUNT(6, 1)
-        const uint32_t card = readlane(rec.y, (int)c) & 0xFFFFu;
-        emit(qd[c], readlane(my_orig, (int)c), (int)(v & 0xFFu), (int)card - tb);
+        for (uint32_t c = 0; c < n; c++) {
+          const uint32_t v = qj[c];
+          DBG_COUNT(7, 1)
+          if (DBG_SKIP(4096u)) { topk_insert(tk, score_bits((double)(v & 0xFFu) + (double)c / 1000.0 + (double)n / 1e6 + (v >> 31 ? 0.5 : 0.0)), qd[c], lane); continue; }
+          if (!(v >> 31)) continue;
+          DBG_COUNT(6, 1)
+          const uint32_t card = readlane(rec.y, (int)c) & 0xFFFFu;
+          emit(qd[c], readlane(my_orig, (int)c), (int)(v & 0xFFu), (int)card - tb);
+        }
+      } else {
+        // Lane c <-> candidate c: verdict, the threshold of the document's own segment and the top-k key of all of them
+        // side by side.  Once the top-k is full, ONE compare per lane against the k-th best leaves the few that can still
+        // enter it (re-filtered whenever one of them does): a prefix or a near-duplicate family with dozens of matches
+        // per query costs a ballot, not a serial insertion attempt per match (autocomplete: 45 % of a wavefront's time).
+        // Documents that repeat a term take the serial path: their secondary entries need the per-list view (emit).
+        const uint32_t v = (uint32_t)lane < n ? qj[lane] : 0u;
+        const int ov = (int)(v & 0xFFu);
+        const int wseg = (int)(rec.y & 0xFFFFu) - tb;
+        const int Tc = __shfl(seg_T, wseg & 63, 64);
+        bool pass = (v >> 31) != 0u && ov >= Tc;
+        DBG_COUNT(7, n)
+        DBG_COUNT(6, popc64(ballot((v >> 31) != 0u)))
+        DBG_COUNT(5, popc64(ballot(pass)))
+        bool dupd = false;
+        if (ix.n_dup_docs && pass) dupd = (ix.dup_bits[my_orig >> 5] >> (my_orig & 31u)) & 1u;
+        uint64_t key;
+        if (kLM) {                                              // lmCollector: ScoreNext is monotone in the continuation count
+          uint32_t myc = 0;
+          uint64_t pm = ballot(pass && !dupd);
+          while (pm) {
+            const int l = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            const uint32_t d = readlane(my_orig, l);
+            uint32_t c;
+            if (lm_small) { const uint64_t mm = ballot(lm_w == d); c = mm ? readlane(lm_c, __builtin_ctzll(mm)) : 0u; }
+            else c = d_lm_count(a.lm_values, lm_from, lm_to, d, lane);
+            if (lane == l) myc = c;
+          }
+          key = (uint64_t)myc;
+        } else if (a.autocomplete) {                            // score = -docID, collector.go:104-106
+          key = ~(uint64_t)my_orig;
+          pass = pass && (dupd || my_orig >= a.ac_first);
+        } else key = score_bits(d_score(a.metric, ov, A, tb + wseg));
+        uint64_t m = ballot(pass && !dupd);
+        while (m) {
+          if (tk.n == k) { m &= ballot(better(key, my_orig, tk.worst_s, tk.worst_id)); if (!m) break; }
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint64_t ks = (uint64_t)readlane((uint32_t)key, l) | ((uint64_t)readlane((uint32_t)(key >> 32), l) << 32);
+          topk_insert(tk, ks, readlane(my_orig, l), lane);
+        }
+        uint64_t dm = ballot(pass && dupd);
+        while (dm) {
+          const int l = __builtin_ctzll(dm);
+          dm &= dm - 1;
+          emit(qd[l], readlane(my_orig, l), (int)(readlane(v, l) & 0xFFu), (int)readlane((uint32_t)wseg, l));
+        }
       }
       __syncthreads();
       }
@@ -1961,11 +2031,10 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
 
 __global__ __launch_bounds__(64) void sg_long_kernel(const BatchArgs a) {
   const int lane = threadIdx.x;
-  const uint32_t n_work = a.q_sel ? __builtin_amdgcn_readfirstlane(*a.q_sel_n) : a.n_q;
+  const uint32_t n_work = min(__builtin_amdgcn_readfirstlane(a.long_list[0]), a.n_q);   // (usually 0: the workgroup leaves at once)
   int slot = -1;
   for (uint32_t b = blockIdx.x; b < n_work; b += gridDim.x) {
-    const uint32_t qi = a.q_sel ? __builtin_amdgcn_readfirstlane(a.q_sel[b]) : b;
-    if (__builtin_amdgcn_readfirstlane(a.out_counts[qi]) != SG_COUNT_TOO_LONG) continue;
+    const uint32_t qi = __builtin_amdgcn_readfirstlane(a.long_list[1u + b]);
     if (slot < 0) {                                              // a slot of the replica's long-query scratch
       if (lane == 0) {
         for (int sidx = (int)(blockIdx.x % SG_LONG_SLOTS);; sidx = (sidx + 1) % SG_LONG_SLOTS) {
