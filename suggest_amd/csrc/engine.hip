@@ -573,18 +573,18 @@ __device__ uint32_t d_lower_bound_u32(const uint32_t* p, uint32_t n, uint32_t ke
 // overlap #{merged lists holding >= j copies} + #{probed lists holding the doc} and is collected if that
 // reaches T; the intersector (n == T) collects the doc once per copy in the shortest list
 // (list_intersector.go:37-70).  fm0/fm1 = query terms (lanes, round 0/1) whose list in the doc's segment
-// holds it.  Writes the extra overlaps to scratch[2*SG_MAX_A+64 ..] and returns their number; `scratch` is the
-// row-table region, idle whenever candidates are emitted (NOT the counters: the overflow pass emits while it
-// still reads them).
+// holds it.  Every extra overlap goes to `emit_extra` as it is found — a document that repeats a term hundreds of times
+// (long documents) has as many secondary entries, the reference keeps them all; `scratch` is the row-table region, idle
+// whenever candidates are emitted (NOT the counters: the overflow pass emits while it still reads them).
 // (A real call would cost the kernel ~100 VGPRs: kept inline.)
-__device__ __forceinline__ int dup_secondary_overlaps(const DeviceIndex& ix, const uint32_t* term, const uint32_t* rows,
-                                                   uint32_t* scratch, int A, uint32_t stride, int w, uint32_t B, int T,
-                                                   uint32_t d, uint64_t fm0, uint64_t fm1, int lane) {
+template <class EmitExtra>
+__device__ __forceinline__ void dup_secondary_overlaps(const DeviceIndex& ix, const uint32_t* term, const uint32_t* rows,
+                                                    uint32_t* scratch, int A, uint32_t stride, int w, uint32_t B, int T,
+                                                    uint32_t d, uint64_t fm0, uint64_t fm1, int lane, EmitExtra&& emit_extra) {
   const uint32_t S32 = ix.S;
   uint32_t* sk = scratch;
   uint32_t* sv = scratch + SG_MAX_A;
   int* stk = (int*)(scratch + 2 * SG_MAX_A);
-  uint32_t* extra = scratch + 2 * SG_MAX_A + 64;
   const int a_rounds = (A + 63) >> 6;
   int n = 0;
   for (int r = 0; r < a_rounds; r++) {
@@ -620,23 +620,21 @@ __device__ __forceinline__ int dup_secondary_overlaps(const DeviceIndex& ix, con
   PairSort ps{sk, sv, stk};
   ps.sort(n);                                           // sort.Sort(rid) by Len
   __syncthreads();
-  int n_extra = 0;
   if (n == T) {                                         // intersector: once per copy in the shortest list
     const int copies = (int)sv[0];
-    for (int c = 1; c < copies && n_extra < 64; c++) extra[n_extra++] = (uint32_t)n;
+    for (int c = 1; c < copies; c++) emit_extra(n);
   } else {
     const int min_q = n - T + 1;
     uint32_t maxm = 0;
     int tail = 0;
     for (int p = 0; p < n; p++) { if (p < min_q) maxm = max(maxm, sv[p]); else tail += sv[p] ? 1 : 0; }
-    for (uint32_t j = 2; j <= maxm && n_extra < 64; j++) {
+    for (uint32_t j = 2; j <= maxm; j++) {
       int c = tail;
       for (int p = 0; p < min_q; p++) c += sv[p] >= j ? 1 : 0;
-      if (c >= T) extra[n_extra++] = (uint32_t)c;
+      if (c >= T) emit_extra(c);
     }
   }
   __syncthreads();
-  return n_extra;
 }
 
 struct TopK {  // wave-uniform state; arrays live in LDS (k <= SG_K_LDS) or in the query's output row
@@ -1108,9 +1106,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           exact_masks(x, w, fm);
           // (which secondary entries CPMerge produces depends on the threshold it ran with: the metric's own, not the tightened one)
           const int T0 = a.autocomplete ? A : d_threshold(a.metric, a.alpha, A, tb + w);
-          const int n_extra = dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T0, d, fm[0], fm[1], lane);
-          const uint32_t* extra = dup_scratch + 2 * SG_MAX_A + 64;
-          for (int x = 0; x < n_extra; x++) offer(d, (int)extra[x], w);
+          dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T0, d, fm[0], fm[1], lane,
+                                 [&](int extra_overlap) { offer(d, extra_overlap, w); });
           __syncthreads();
           build_qhash();                                    // (the scratch lay over it)
         }
@@ -1788,24 +1785,16 @@ __device__ __forceinline__ uint32_t long_gram_hash(const uint32_t* runes, uint32
   return (uint32_t)h;
 }
 
-__device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int lane) {
-  const DeviceIndex& ix = a.ix;
+// The tokeniser of NewSuggestTokenizer / NewAutocompleteTokenizer (pkg/suggest/tokenizer.go:9-34) for texts of any length
+// up to SG_LONG_MAX_TERMS bytes, with its tables in an HBM slot: wrap -> lower -> trim -> q-grams (first-occurrence
+// dedup) -> normalise.  Returns the number of n-grams; their packed keys are in the slot's `keys`.  Shared by the
+// long-query kernel and the device index builder's long documents.
+__device__ uint32_t long_tokenize(const DeviceIndex& ix, bool autocomplete, const uint8_t* q, uint32_t qlen, uint8_t* slot, int lane) {
   uint32_t* runes = (uint32_t*)(slot + LongSlot::o_runes);
   uint64_t* keys = (uint64_t*)(slot + LongSlot::o_keys);
-  uint32_t* term = (uint32_t*)(slot + LongSlot::o_term);
   uint32_t* htab = (uint32_t*)(slot + LongSlot::o_hash);
-  uint32_t* sk = (uint32_t*)(slot + LongSlot::o_sk);
-  uint32_t* sv = (uint32_t*)(slot + LongSlot::o_sv);
-  int* stk = (int*)(slot + LongSlot::o_stk);
-  uint32_t* extra = (uint32_t*)(slot + LongSlot::o_extra);
-  uint32_t* cnt = (uint32_t*)(slot + LongSlot::o_cnt);
-  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
-  const uint8_t* q = a.q_blob + qb;
-  const uint64_t qlen64 = qe - qb;
-  if (qlen64 > SG_LONG_MAX_TERMS) return;                       // stays SG_COUNT_TOO_LONG
-  const uint32_t qlen = (uint32_t)qlen64, k = a.k;
   // ---- wrap -> lower -> runes (the same uniform sequential decode as the wavefront kernel's rare path; ASCII in parallel) ----
-  const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete ? 0u : ix.n_wrap1;
+  const uint32_t n_w0 = ix.n_wrap0, n_w1 = autocomplete ? 0u : ix.n_wrap1;
   bool na = false;
   for (uint32_t i = lane; i < qlen; i += 64) na |= q[i] >= 0x80;
   uint32_t R = 0, byte_len = 0;
@@ -1872,6 +1861,23 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
     }
   }
   __syncthreads();
+  return A;
+}
+
+__device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int lane) {
+  const DeviceIndex& ix = a.ix;
+  uint64_t* keys = (uint64_t*)(slot + LongSlot::o_keys);
+  uint32_t* term = (uint32_t*)(slot + LongSlot::o_term);
+  uint32_t* sk = (uint32_t*)(slot + LongSlot::o_sk);
+  uint32_t* sv = (uint32_t*)(slot + LongSlot::o_sv);
+  int* stk = (int*)(slot + LongSlot::o_stk);
+  uint32_t* cnt = (uint32_t*)(slot + LongSlot::o_cnt);
+  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
+  const uint8_t* q = a.q_blob + qb;
+  const uint64_t qlen64 = qe - qb;
+  if (qlen64 > SG_LONG_MAX_TERMS) return;                       // stays SG_COUNT_TOO_LONG
+  const uint32_t qlen = (uint32_t)qlen64, k = a.k;
+  const uint32_t A = long_tokenize(ix, a.autocomplete != 0, q, qlen, slot, lane);
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
   if (ix.slots) for (uint32_t i = lane; i < A; i += 64) term[i] = d_term_lookup(ix, keys[i]);
   __syncthreads();
@@ -1985,24 +1991,20 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
           __threadfence();
           __syncthreads();
           const int T0 = a.autocomplete ? (int)A : d_threshold(a.metric, a.alpha, (int)A, B);
-          int n_extra = 0;
           if ((int)n == T0) {
             const int copies = (int)sv[0];
-            for (int c2 = 1; c2 < copies && n_extra < 64; c2++) { if (lane == 0) extra[n_extra] = n; n_extra++; }
+            for (int c2 = 1; c2 < copies; c2++) offer((int)n);
           } else if ((int)n > T0) {
             const int min_q = (int)n - T0 + 1;
             uint32_t maxm = 0;
             int tail = 0;
             for (int pp = 0; pp < (int)n; pp++) { if (pp < min_q) maxm = max(maxm, sv[pp]); else tail += sv[pp] ? 1 : 0; }
-            for (uint32_t jj = 2; jj <= maxm && n_extra < 64; jj++) {
+            for (uint32_t jj = 2; jj <= maxm; jj++) {
               int c2 = tail;
               for (int pp = 0; pp < min_q; pp++) c2 += sv[pp] >= jj ? 1 : 0;
-              if (c2 >= T0) { if (lane == 0) extra[n_extra] = (uint32_t)c2; n_extra++; }
+              if (c2 >= T0) offer(c2);
             }
           }
-          __threadfence();
-          __syncthreads();
-          for (int e2 = 0; e2 < n_extra; e2++) offer((int)extra[e2]);
           __syncthreads();
         }
       }

@@ -414,14 +414,21 @@ def test_device_index_build_is_identical_to_host_build(cars_lines, words_lines):
     assert_same(dev.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10), ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
 
 
-def test_device_index_build_rejects_documents_beyond_the_tokeniser():
+def test_device_index_build_takes_long_documents():
+    """Writer.AddDocument has no limit on a document's n-grams (indexer_writer.go:66-86): the device builder hands documents
+    above the LDS tokeniser's 128 n-grams to its long tokeniser and produces the host builder's arrays; only a document
+    above 65 536 bytes is refused (and the host builder takes that one)."""
     from suggest_amd import NGramIndex, IndexDescription, synth
     import random
     rnd = random.Random(5)
     long_doc = bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(400))
+    docs = [b"short", long_doc, long_doc[:129], long_doc[100:300] * 3, b"abc" * 200]
+    host = NGramIndex(docs, IndexDescription(**synth.DESCRIPTION), upload=False)
+    assert NGramIndex(docs, IndexDescription(**synth.DESCRIPTION), upload=False, build="device").digest() == host.digest()
+    huge = long_doc * 170                                               # 68 000 bytes
     with pytest.raises(Exception, match="sg_index_build"):
-        NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False, build="device")
-    NGramIndex([b"short", long_doc], IndexDescription(**synth.DESCRIPTION), upload=False)      # the host builder takes it
+        NGramIndex([b"short", huge], IndexDescription(**synth.DESCRIPTION), upload=False, build="device")
+    NGramIndex([b"short", huge], IndexDescription(**synth.DESCRIPTION), upload=False)             # the host builder takes it
 
 
 def test_doc_sharded_index_merges_to_the_unsharded_result():
@@ -505,6 +512,10 @@ def test_long_queries_are_answered_on_the_device():
     docs += [docs[410] + "x", docs[410][:-3], docs[420][5:] + "tail"]
     gpu = NGramIndex(docs, IndexDescription(**desc))
     ora = oracle.OracleIndex(docs, **desc)
+    # the device index builder takes the long documents too (Writer.AddDocument has no limit, indexer_writer.go:66-86):
+    # same arrays as the host build, and the same answers from the store it leaves in HBM
+    dev_built = NGramIndex(docs, IndexDescription(**desc), build="device")
+    assert dev_built.digest() == gpu.digest()
 
     def edit(s):
         s = list(s)
@@ -521,6 +532,7 @@ def test_long_queries_are_answered_on_the_device():
     qb, qo = oracle.pack_strings(queries)
     for metric, a, k in (("jaccard", 0.5, 5), ("cosine", 0.3, 10), ("dice", 0.4, 100), ("overlap", 0.6, 7), ("cosine", 0.2, 70)):
         assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k), ora.suggest_batch(qb, qo, metric, a, k), queries)
+    assert_same(dev_built.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.3, k=10), ora.suggest_batch(qb, qo, "cosine", 0.3, 10), queries)
     # autocomplete: every n-gram of the prefix must be in the document
     prefixes = [d[:rng.randint(130, 200)] for d in docs[400:460] if len(d) > 210] + [docs[10][:4], docs[405][:131]]
     pb, po = oracle.pack_strings(prefixes)

@@ -41,7 +41,7 @@ def make_trial(seed, scale=1):
         if len(oracle.OracleIndex([docs[0]], **desc).tokenize(docs[0])) == 0:
             return None
     env = {name: rng.choice(choices) for name, choices in KNOBS}
-    build = rng.choice(["host", "device"]) if max_len <= 60 else "host"
+    build = rng.choice(["host", "device"])
     queries = [rng.choice(docs) for _ in range(30)] + ["".join(rng.choice(syms) for _ in range(rng.randint(0, max_len + 6))) for _ in range(30)]
     queries += [d[:rng.randint(0, len(d))] + rng.choice(syms) + d[rng.randint(0, len(d)):] for d in rng.sample(docs, min(20, len(docs)))]
     searches = []
@@ -49,7 +49,17 @@ def make_trial(seed, scale=1):
         metric = rng.choice(["jaccard", "cosine", "dice", "overlap", "exact"])
         a = 1.0 if metric == "exact" else rng.choice([0.15, 0.3, 0.5, 0.7, 0.9, 1.0])
         searches.append((metric, a, rng.choice([1, 2, 5, 10, 64, 65, 300])))
-    return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=rng.choice([1, 7, 100]), syms=syms)
+    limit = rng.choice([1, 7, 100])
+    # (round 3, drawn last so that the trials of older seeds keep their content) long documents and queries — above the
+    # wavefront kernel's 128 n-grams: sg_long_kernel — and k above the former 1024
+    if rng.random() < 0.2:
+        long_docs = ["".join(rng.choice(syms) for _ in range(rng.randint(130, 600))) for _ in range(rng.randint(1, 12))]
+        docs += long_docs
+        queries += [d[:rng.randint(100, len(d))] for d in long_docs] + [long_docs[0] + rng.choice(syms) * rng.randint(1, 300)]
+        queries += [d[:60] + rng.choice(syms) + d[61:] for d in long_docs[:4]]
+        if rng.random() < 0.5:
+            searches.append((rng.choice(["jaccard", "cosine", "dice"]), rng.choice([0.2, 0.5, 0.8]), rng.choice([1500, 3000])))
+    return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
 def run_trial(t, verbose=False, only=None, k_override=None):
