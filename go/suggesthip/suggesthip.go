@@ -36,8 +36,8 @@ type Builder struct {
 	// Devices, when set, gets one replica of the index per listed GPU (sg_index_replicate: ONE host build) and batches
 	// are cut into contiguous slices over them (sg_suggest_batch_multi) — SURVEY.md 8e, no collective.
 	Devices []int
-	// OnDevice builds the index on the GPU (sg_index_build_device: same arrays, ~16x faster at 10 M strings); documents
-	// with more than 128 n-grams make it fall back to the host builder.
+	// OnDevice builds the index on the GPU (sg_index_build_device: same arrays, ~16x faster at 10 M strings); a dictionary
+	// beyond its limits (a document above 65 536 bytes, 2^26 documents) falls back to the host builder.
 	OnDevice bool
 }
 
@@ -72,7 +72,7 @@ func (b *Builder) Build() (suggest.NGramIndex, error) {
 		bp = (*C.uint8_t)(unsafe.Pointer(&blob[0]))
 	}
 	built := false
-	if b.OnDevice { // documents with more than 128 n-grams are beyond the device builder: SG_E_UNSUPPORTED, then the host's
+	if b.OnDevice { // a dictionary beyond the device builder's limits: SG_E_UNSUPPORTED, then the host's
 		runtime.LockOSThread()
 		rc := C.sg_index_build_device(bp, &offs[0], C.uint32_t(len(offs)-1), desc, C.int(b.Device), &h)
 		if rc != 0 && rc != C.SG_E_UNSUPPORTED {
