@@ -143,17 +143,22 @@ class Env:
         if self.single_device:
             self.local_rank = 0
         self.backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
+        self.nccl_group = None
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # The path has no data-path collective: barriers and the max over the ranks' clocks are control plane and go over
+            # gloo (CPU) — a rank that waits for another keeps no spinning kernel on its GPU, and an RCCL problem on the node
+            # cannot take the measurement with it.  RCCL is only needed for the optional gather of the result rows: a group of
+            # its own, made lazily, checked once outside the timed region (config.rccl_gather_check).
+            dist.init_process_group("gloo")
+            self.nccl_group = None
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-                # (waiting for rank 0's single-process replica leg must not keep a spinning RCCL kernel on every GPU)
-                self.cpu_group = dist.new_group(backend="gloo")
-            else:
-                dist.init_process_group(self.backend)
-                self.cpu_group = None
+                try:
+                    self.nccl_group = dist.new_group(backend="nccl")
+                except Exception as exc:
+                    self.log("no RCCL group (%r): the optional result gather is skipped" % (exc,))
 
     def log(self, *a):
         if self.rank == 0:
@@ -214,9 +219,9 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
 
     def gather(b, force=False):
         if world > 1 and (args.gather or force):   # top-k gather over RCCL/xGMI: k*(u32,f64) per query
-            dist.all_gather_into_tensor(g_ids, d_ids[b])
-            dist.all_gather_into_tensor(g_sc, d_sc[b])
-            dist.all_gather_into_tensor(g_cnt, d_cnt[b])
+            dist.all_gather_into_tensor(g_ids, d_ids[b], group=env.nccl_group)
+            dist.all_gather_into_tensor(g_sc, d_sc[b], group=env.nccl_group)
+            dist.all_gather_into_tensor(g_cnt, d_cnt[b], group=env.nccl_group)
 
     for i in range(warmup):
         step(i % n_b)
@@ -233,7 +238,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     alg_timed = float(np.mean([alg[i % n_b] for i in range(steps)]))       # algorithmic bytes per launch, timed launches
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if env.backend == "nccl" else "cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -279,7 +284,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             log("replicas leg failed: %r" % (exc,))
             replicas = {"error": repr(exc)}
     if replicas_leg and world > 1:
-        dist.barrier(group=env.cpu_group)
+        dist.barrier()
 
     # ---- CPU baseline: the oracle (restatement of the Go path) on this host, rank 0, N=1 only ----
     cpu = None
