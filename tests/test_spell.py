@@ -111,6 +111,7 @@ def test_predict_reference_fixture(g):
 def test_predict_synthetic_language_model(tmp_path):
     """A 20 000-word vocabulary with families of similar words and a random bigram/trigram corpus: contexts with many
     continuations (64-ary search over several rounds), prefixes with hundreds of completions, ties, unknown words."""
+    import torch  # noqa: F401  (before the library: both must resolve the same libamdhip64, suggest_amd/_lib.py)
     from suggest_amd import LanguageModel, SpellChecker, synth
     blob, offs = synth.make_dict(20000, seed=51, families=3)
     vocab = sorted(set(w.decode() for w in synth.unpack(blob, offs)))
@@ -147,6 +148,32 @@ def test_predict_synthetic_language_model(tmp_path):
         queries.append((" ".join(ctx + [word])).encode())
     for top_k, sim in ((5, 0.5), (20, 0.4), (1, 0.7)):
         _assert_same_predictions(sc, ora_lm, ora_ix, queries, top_k, sim)
+    # the word tokeniser runs on the device (spell_tokenize_kernel): texts a keyboard produces — upper case, separators of
+    # every kind between and around the words, several in a row, non-ASCII runes outside the model's alphabet, invalid
+    # UTF-8, a text that ends in separators (the last word is then the one before them), nothing but separators
+    messy = []
+    for i, q in enumerate(queries[:200]):
+        w = q.decode().split(" ")
+        sep = [" ", "  ", ", ", " - ", "\t", ". ", "! ", " \u00e9 ", " \u4e2d "][i % 9]
+        t = sep.join(x.upper() if (i + j) % 3 == 0 else x for j, x in enumerate(w))
+        t = ["", " ", "...", "\u00ab"][i % 4] + t + ["", " ", "!!", " ?", "\u00bb "][i % 5]
+        messy.append(t.encode("utf-8"))
+    messy += [b"", b"   ", b"?!", b"\xff\xfe", b"abc\xffdef ghi", vocab[5].encode() + b"\xc3", (vocab[7] + " " + vocab[8]).encode() + b"\xe2\x82"]
+    _assert_same_predictions(sc, ora_lm, ora_ix, messy, 5, 0.5)
+    # the device-resident entry point gives the rows of the host-buffer one
+    import torch
+    from suggest_amd.index import pack_strings
+    dev = torch.device("cuda", 0)
+    qb, qo = pack_strings(queries + messy)
+    n, k = len(qo) - 1, 5
+    h_ids, h_cnt = sc.predict_batch(blob=qb, offs=qo, top_k=k, similarity=0.5)
+    d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to(dev)
+    d_ids = torch.full((n, k + 1), 7, dtype=torch.int32, device=dev); d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    sc.predict_batch_device(d_q.data_ptr(), d_o.data_ptr(), n, int(qo[-1]), k, 0.5, d_ids.data_ptr(), d_cnt.data_ptr(),
+                            stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(d_cnt.cpu().numpy().view(np.uint32), h_cnt)
+    assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), h_ids)
 
 
 def _gram_files(directory, order=3):
