@@ -13,22 +13,30 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, int iters) {
   for (int i = lane; i < 2048; i += 64) cnt[i] = 0;
   __syncthreads();
   const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32*)cnt;
+  // the 14 addresses of a lane are drawn once (the loop below issues nothing but the atomics, one wait and the max: it
+  // measures the LDS, not an address generator)
   uint32_t x = (blockIdx.x * 64 + lane) * 2654435761u + 12345u, acc = 0;
+  uint32_t addr[14];
+#pragma unroll
+  for (int e = 0; e < 14; e++) {
+    x = x * 1664525u + 1013904223u;
+    if (MODE == 1) addr[e] = (((uint32_t)lane * 4u + (uint32_t)e * 256u) & 8188u) | cbase;      // lane-linear: conflict-free
+    else addr[e] = ((x >> 8) & 8188u) | cbase;                                                     // random word
+  }
+  const int active = MODE == 3 ? 16 : MODE == 4 ? 32 : MODE == 5 ? 8 : 64;
   for (int it = 0; it < iters; it++) {
     uint32_t old[14];
 #pragma unroll
     for (int e = 0; e < 14; e++) {
-      x = x * 1664525u + 1013904223u;
-      uint32_t a;
-      if (MODE == 1) a = ((uint32_t)lane * 4u + (uint32_t)e * 256u) & 8188u;        // lane-linear: conflict-free
-      else a = (x >> 8) & 8188u;                                                       // random word
-      lds_u32* w = (lds_u32*)(uintptr_t)(a | cbase);
-      if (MODE == 2) { __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); old[e] = 0; }
-      else old[e] = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      lds_u32* w = (lds_u32*)(uintptr_t)addr[e];
+      old[e] = 0;
+      if (MODE == 2) __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (lane < active) old[e] = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
     for (int e = 0; e < 14; e++) acc = max(acc, old[e]);
+    asm volatile("" : "+v"(acc));
   }
   if (acc == 0xFFFFFFFFu) out[0] = acc + cnt[lane];
 }
@@ -49,5 +57,8 @@ int main() {
   run<0>("random, with return", d);
   run<1>("lane-linear, with return", d);
   run<2>("random, no return", d);
+  run<4>("random, 32 of 64 lanes (EXEC)", d);
+  run<3>("random, 16 of 64 lanes (EXEC)", d);
+  run<5>("random, 8 of 64 lanes (EXEC)", d);
   return 0;
 }
