@@ -577,3 +577,31 @@ def test_autocomplete_pages_through_every_match(golden_dir):
                 continue
             assert gpu.autocomplete_all(prefix, page=page) == want
     assert len(ora.autocomplete_batch(*oracle.pack_strings([b"a"]), len(words))[0]) > 0
+
+
+def test_rows_do_not_depend_on_how_a_batch_is_cut(synth_small):
+    """A query's row is the same whatever batch it travels in: one call of 36 867 queries (ordered by length on the
+    device, above the 8192-query threshold of the order kernels) against the same queries in calls of 8000, and the
+    oracle's rows on a sample."""
+    from suggest_amd import synth
+    gpu, ora, _, _ = synth_small
+    blob, offs = synth.make_dict(50000, seed=1)
+    n = 16384 * 2 + 4099                          # uneven pieces
+    qb, qo = synth.make_queries(n, blob, offs, seed=5)
+    ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=7)
+    aid, acnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=5)
+    for lo in range(0, n, 8000):
+        hi = min(n, lo + 8000)
+        so = (qo[lo:hi + 1] - qo[lo]).astype(np.uint64)
+        sb = qb[int(qo[lo]):int(qo[hi])]
+        i2, s2, c2 = gpu.suggest_batch(blob=sb, offs=so, metric="jaccard", similarity=0.5, k=7)
+        assert_same((ids[lo:hi], sc[lo:hi], cnt[lo:hi]), (i2, s2, c2))
+        a2, ac2 = gpu.autocomplete_batch(blob=sb, offs=so, limit=5)
+        assert (acnt[lo:hi] == ac2).all()
+        valid = np.arange(5)[None, :] < np.minimum(ac2, 5)[:, None]
+        assert (aid[lo:hi][valid] == a2[valid]).all()
+    pick = np.arange(0, n, 37)
+    po = np.zeros(len(pick) + 1, np.uint64)
+    po[1:] = np.cumsum(qo[pick + 1] - qo[pick])
+    pb = np.concatenate([qb[int(qo[i]):int(qo[i + 1])] for i in pick])
+    assert_same((ids[pick], sc[pick], cnt[pick]), ora.suggest_batch(pb, po, "jaccard", 0.5, 7))
