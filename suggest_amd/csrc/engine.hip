@@ -156,7 +156,8 @@ struct BatchArgs {
   uint32_t* long_list;    // [1 + n_q] the wavefront kernel's list of such queries: [0] = how many (zeroed per launch), then their indices
   uint32_t long_max_seg;  // documents of the largest cardinality segment (the slot's counter array)
   uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
-  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative, one query in 32
+  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative
+  uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -972,7 +973,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     __syncthreads();
     // ---- lane w owns segment tb+w: posting volume, present terms, threshold.  kTight: computed again (for the segments
     //      still to come, w >= w_start) whenever the k-th best score has moved: the thresholds tighten with it. ----
-    if (kTight && lane == 0) tile_state[2] = 0u;
+    // kTight: the segments from the query's own cardinality upwards go first, those below it second — the reference walks
+    // the window inside-out for the same reason (suggester.go:64-75): the best matches sit next to |A|, the top-k fills
+    // with them and the thresholds of everything further out tighten before it is streamed.  (Ascending from b_min, a low
+    // similarity over a dictionary of near-duplicates filled the top-k with the worst admissible documents first: a
+    // million verifications per query.)  The result does not depend on the order: the top-k's order is total.
+    const bool may_split = splitting && primary && k <= SG_K_LDS && qi < a.slot_cap;
+    int h_n = 1, h_lo[2] = {0, 0}, h_hi[2] = {Wt, Wt};
+    if (kTight && !may_split && !a.autocomplete && A > tb && A - tb < Wt) { h_n = 2; h_lo[0] = A - tb; h_hi[1] = A - tb; }
+    for (int half = 0; half < h_n; half++) {
+    if (kTight && lane == 0) tile_state[2] = (uint32_t)h_lo[half];
     for (;;) {
     int w_start = 0;
     if (kTight) { __syncthreads(); w_start = (int)tile_state[2]; }
@@ -993,7 +1003,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           seg_valid = seg_T <= A;
         }
       }
-      seg_valid = seg_valid && (int)ne >= seg_T && (!kTight || lane >= w_start);   // searcher.go:32 (fewer present terms than T)
+      seg_valid = seg_valid && (int)ne >= seg_T && (!kTight || (lane >= w_start && lane < h_hi[half]));   // searcher.go:32 (fewer present terms than T)
     }
     const uint64_t vmask = ballot(seg_valid);
     if (kTight && lane == 0) {                                       // the k-th best score these thresholds were tightened against
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     //      is cut into parts of consecutive segments of about equal volume, which are queued for the second launch;
     //      this wavefront goes on with the next tile.  A lone heavy query would otherwise be one wavefront's serial
     //      work (skewed dictionaries: 40x the mean) and set the batch's latency. ----
-    if (splitting && primary && k <= SG_K_LDS && qi < a.slot_cap && (!kTight || w_start == 0)) {
+    if (may_split && (!kTight || w_start == 0)) {
       const uint32_t vol = seg_valid ? seg_tot : 0u;
       const uint32_t incl = wave_scan_incl(vol, lane);
       const uint32_t total = readlane(incl, 63);
@@ -1251,7 +1261,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         uint64_t key;
         if (kLM) {                                              // lmCollector: ScoreNext is monotone in the continuation count
           uint32_t myc = 0;
-          uint64_t pm = ballot(pass && !dupd);
+          uint64_t pm = ballot(pass);
           while (pm) {
             const int l = __builtin_ctzll(pm);
             pm &= pm - 1;
@@ -1274,8 +1284,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           const uint64_t ks = (uint64_t)readlane((uint32_t)key, l) | ((uint64_t)readlane((uint32_t)(key >> 32), l) << 32);
           topk_insert(tk, ks, readlane(my_orig, l), lane);
         }
+        // (a document that repeats a term: its secondary entries have its own docID and at most the primary entry's overlap —
+        //  none of them enters a full top-k the primary does not; the per-list view and the pair sort, ~60 us, only for the rest)
         uint64_t dm = ballot(pass && dupd);
         while (dm) {
+          if (tk.n == k) { dm &= ballot(better(key, my_orig, tk.worst_s, tk.worst_id)); if (!dm) break; }
           const int l = __builtin_ctzll(dm);
           dm &= dm - 1;
           emit(qd[l], readlane(my_orig, l), (int)(readlane(v, l) & 0xFFu), (int)readlane((uint32_t)wseg, l));
@@ -1671,6 +1684,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     if (!kTight || !again) break;
     }  // segment statistics, again after a tightening
+    }  // the two halves of the tile
   }
 
   // ---- a part of a split query hands its top-k over; the part that finishes last merges them all (top-k of a
@@ -1728,7 +1742,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
-  if (!kLM && !a.autocomplete && a.fill_stat && lane == 0 && (qi & 31u) == 0u) {
+  if (!kLM && !a.autocomplete && a.fill_stat && lane == 0 && (qi & a.fill_mask) == 0u) {
     atomicAdd(a.fill_stat + 1, 1u);
     if (n == k) atomicAdd(a.fill_stat, 1u);
     if (n) atomicAdd(a.fill_stat + 2, n);
@@ -1933,11 +1947,17 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
       const uint32_t j = j0 + (uint32_t)lane;
       const uint32_t c = j < n_seg ? ld_l2(cnt + j) : 0u;
       uint64_t m = ballot(c >= (uint32_t)T);
+      if (!m) continue;
+      // lane <-> candidate: docID and top-k key side by side; once the top-k is full one compare per lane leaves the few that
+      // can still enter it (and with them their secondary entries: same docID, at most the same overlap)
+      const uint32_t dj = ((m >> lane) & 1ull) ? ix.orig_of[x0 + j] : 0u;
+      const uint64_t keyj = a.autocomplete ? ~(uint64_t)dj : score_bits(d_score(a.metric, (int)c, (int)A, B));
       while (m) {
+        if (!a.lm_values && tk.n == k) { m &= ballot(better(keyj, dj, tk.worst_s, tk.worst_id)); if (!m) break; }
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const uint32_t x = x0 + j0 + (uint32_t)l, ov = readlane(c, l);
-        const uint32_t d = __builtin_amdgcn_readfirstlane(ix.orig_of[x]);
+        const uint32_t d = readlane(dj, l);
         auto offer = [&](int overlap) {
           if (a.lm_values) topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
           else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }

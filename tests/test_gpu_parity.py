@@ -559,6 +559,31 @@ def test_fuzz_regressions(seed, monkeypatch):
     assert fz.run_trial(t) == []
 
 
+def test_low_similarity_over_near_duplicates_stays_fast():
+    """Fuzz trial 4200037 (scale 10): 200 012 near-duplicate documents over eight letters, Dice >= 0.15 / Overlap >= 0.3,
+    97 queries of which 13 are above 128 n-grams.  It took the device 640 s (the CPU oracle: 6 s): the top-k filled with
+    the worst admissible documents first and a million postings per query were verified, every document that repeats a
+    term through the per-list path.  Thresholds that follow the top-k from the first launch on (similarity < 0.3), the
+    segments next to |A| first, and one compare against the k-th best before the per-list path: 1 s.  Parity as ever."""
+    import importlib.util, time
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    t = fz.make_trial(4200037, 10)
+    t["env"] = {}
+    from suggest_amd import IndexDescription, NGramIndex
+    gpu = NGramIndex(t["docs"], IndexDescription(**t["desc"]), build="host")
+    qb, qo = oracle.pack_strings(t["queries"])
+    t0 = time.time()
+    for metric, a, k in t["searches"]:
+        gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k)
+    gpu.autocomplete_batch(blob=qb, offs=qo, limit=t["limit"])
+    took = time.time() - t0
+    gpu.close()
+    assert took < 30.0, took
+    assert fz.run_trial(t) == []
+
+
 def test_autocomplete_pages_through_every_match(golden_dir):
     """The reference's Autocomplete streams EVERY match to the caller's collector (pkg/suggest/autocomplete.go:40-77); a
     binding gets them all by paging (sg_autocomplete_one_from: the `limit` smallest docIDs >= first_doc)."""

@@ -67,20 +67,28 @@ def run_trial(t, verbose=False, only=None, k_override=None):
     import oracle
     from suggest_amd import IndexDescription, NGramIndex
     os.environ.update(t["env"])
+    tm = t.setdefault("timing", {"gpu": 0.0, "oracle": 0.0})
+    t0 = time.time()
     try:
         gpu = NGramIndex(t["docs"], IndexDescription(**t["desc"]), build=t["build"])
     except Exception as exc:      # a description whose terms do not fit the 64-bit key is refused, not answered
         if "fit" in str(exc) or "-2" in str(exc):
             return []
         raise
+    tm["gpu"] += time.time() - t0
+    t0 = time.time()
     ora = oracle.OracleIndex(t["docs"], **t["desc"])
+    tm["oracle"] += time.time() - t0
     queries = t["queries"] if only is None else [t["queries"][only]]
     qb, qo = oracle.pack_strings(queries)
     out = []
     for metric, a, k in t["searches"]:
         k = k_override or k
+        t0 = time.time()
         ids, sc, cnt = gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k)
+        t1 = time.time()
         oi, os_, oc, _ = ora.suggest_batch(qb, qo, metric, a, k)
+        tm["gpu"] += t1 - t0; tm["oracle"] += time.time() - t1
         valid = (np.arange(k)[None, :] < np.minimum(oc, k)[:, None]) & (oc < 0xFFFFFFF0)[:, None]
         rows = np.nonzero((cnt != oc) | (valid & ((ids != oi) | (sc.view(np.uint64) != os_.view(np.uint64)))).any(axis=1))[0]
         if verbose:
@@ -93,8 +101,11 @@ def run_trial(t, verbose=False, only=None, k_override=None):
             out.append("%s a=%.2f k=%d rows=%s query=%r (%d tokens) counts gpu/oracle %d/%d, first difference at rank %d: gpu %s oracle %s"
                        % (metric, a, k, rows[:5].tolist(), queries[r], len(ora.tokenize(queries[r])), int(cnt[r]), int(oc[r]), first,
                           g[first:first + 2], o[first:first + 2]))
+    t0 = time.time()
     ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=t["limit"])
+    t1 = time.time()
     oi, oc, _ = ora.autocomplete_batch(qb, qo, t["limit"])
+    tm["gpu"] += t1 - t0; tm["oracle"] += time.time() - t1
     valid = np.arange(t["limit"])[None, :] < np.minimum(oc, t["limit"])[:, None]
     if not (np.array_equal(cnt, oc) and np.array_equal(ids[valid], oi[valid])):
         out.append("autocomplete limit=%d" % t["limit"])
@@ -131,8 +142,10 @@ def main():
         for m in run_trial(t):
             bad += 1
             print("MISMATCH seed %d: %s env=%s build=%s: %s" % (seed, t["desc"], t["env"], t["build"], m), flush=True)
-        if time.time() - t0 > 5:
-            print("slow trial: seed %d took %.1f s: %s, %d docs, syms %r" % (seed, time.time() - t0, t["desc"], len(t["docs"]), t["syms"]), flush=True)
+        tm = t.get("timing", {"gpu": 0.0, "oracle": 0.0})
+        if time.time() - t0 > 5 or tm["gpu"] > 1.0:
+            print("slow trial: seed %d took %.1f s (device side %.2f s, oracle %.2f s): %s, %d docs, syms %r, searches %s, env %s"
+                  % (seed, time.time() - t0, tm["gpu"], tm["oracle"], t["desc"], len(t["docs"]), t["syms"], t["searches"], t["env"]), flush=True)
     print("fuzz: %d trials, %d mismatches" % (trial, bad))
     sys.exit(1 if bad else 0)
 
