@@ -1,5 +1,7 @@
+"""Phase shares and event counts (SG_PHASE_TIMING build) of two queries of fuzz trial 4200037 x10 — DESIGN.md §4.8.
+GPU box, after `make -C suggest_amd/csrc prof`:  [SG_TIGHTEN=0|1|2] python tools/slow_trial_phases.py"""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 from suggest_amd import _lib

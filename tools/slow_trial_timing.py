@@ -1,5 +1,7 @@
+"""Device time of a fuzz trial's searches, short and long queries apart.
+GPU box:  python tools/slow_trial_timing.py SEED SCALE [default]   (default: without the trial's SG_* knobs)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import fuzz_parity as fp, oracle, numpy as np
