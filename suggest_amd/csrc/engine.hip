@@ -156,6 +156,9 @@ struct BatchArgs {
   uint32_t* long_list;    // [1 + n_q] the wavefront kernel's list of such queries: [0] = how many (zeroed per launch), then their indices
   uint32_t long_max_seg;  // documents of the largest cardinality segment (the slot's counter array)
   uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
+  // ---- the tokeniser as a launch of its own (sg_terms_kernel, big batches): the search kernel then starts from the term ids ----
+  int32_t* pre_A;         // [n_q] d_tokenize's result per query (null: the search kernel tokenises itself)
+  uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative
   uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
@@ -881,7 +884,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     __syncthreads();
   }
   do {   // one query (or one part of one): `break` leaves it
-  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
   const uint32_t lm_from = kLM ? a.lm_from[qi] : 0u, lm_to = kLM ? a.lm_to[qi] : 0u;
   // The continuations of the query's context, one (word << 32 | count) per lane when there are at most 64 of them (the
   // usual case: a bigram context of a 50 M-token model has a handful): ScoreNext of a candidate is then a compare across
@@ -894,7 +896,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   double* out_scores = a.out_scores ? a.out_scores + (uint64_t)qi * k : nullptr;
 
   if (DBG_SKIP(32u)) { if (lane == 0) a.out_counts[qi] = 0; break; }
-  const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
+  int A;
+  if (a.pre_A) {
+    // sg_terms_kernel has tokenised the batch: the term ids are one coalesced read (issued together with the count)
+    // instead of the tokeniser's chain of dependent round trips — offsets, bytes, term table — at the head of every query
+    const uint32_t* pt = a.pre_terms + (uint64_t)qi * SG_MAX_A;
+    const uint32_t t0 = pt[lane];
+    A = __builtin_amdgcn_readfirstlane(a.pre_A[qi]);
+    if (lane < A) term[lane] = t0;
+    if (A > 64 && 64 + lane < A) term[64 + lane] = pt[64 + lane];
+    __syncthreads();
+  } else {
+    const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
+    A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), runes, keys, term, lane);
+  }
   PH(0)
   if (DBG_SKIP(64u)) { if (lane == 0) a.out_counts[qi] = (uint32_t)A; break; }
   if (A < 0) {                                                 // beyond this kernel's tables: flagged, and listed for sg_long_kernel
@@ -1747,7 +1762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (n == k) atomicAdd(a.fill_stat, 1u);
     if (n) atomicAdd(a.fill_stat + 2, n);
   }
-  if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 2] = (uint32_t)(qe - qb); out_ids[k - 3] = qi; out_ids[k - 4] = (uint32_t)qb; }
+  if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 3] = qi; }
   PH(7)
   } while (0);
   if (!kParts) break;
@@ -1755,6 +1770,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The tokeniser as a launch of its own (batches large enough to fill the machine): one wavefront per query runs
+// d_tokenize — wrap, lower, trim, q-grams, appendUnique, normalise, term table (pkg/suggest/tokenizer.go:9-34,
+// pkg/analysis/ngram_tokenizer.go:17-55) — and leaves A and the term ids in HBM.  Inside the search kernel the same
+// steps are four dependent memory round trips at the head of every query with 12 wavefronts per CU to hide them (9 % of
+// a wavefront's time on the headline, more on small dictionaries); here the wavefronts need 2 KB of LDS and few
+// registers, so a CU holds 32 of them and the round trips overlap.  Same function, same results.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sg_terms_kernel(const BatchArgs a) {
+  __shared__ uint32_t s_runes[SG_MAX_RUNES];
+  __shared__ uint64_t s_keys[SG_MAX_A];
+  __shared__ uint32_t s_term[SG_MAX_A];
+  const int lane = threadIdx.x;
+  uint32_t qi = blockIdx.x;
+  if (a.q_sel) {                                             // a launch over a subset of the batch: the same subset
+    if (qi >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) return;
+    qi = __builtin_amdgcn_readfirstlane(a.q_sel[qi]);
+  }
+  const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
+  const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), s_runes, s_keys, s_term, lane);
+  if (lane == 0) a.pre_A[qi] = A;
+  for (int i = lane; i < A; i += 64) a.pre_terms[(uint64_t)qi * SG_MAX_A + i] = s_term[i];
+}
 
 // ------------------------------------------------------------------------------------------
 // Queries beyond the wavefront kernel's tables (more than SG_MAX_A n-grams / SG_MAX_RUNES runes).  The reference has no

@@ -139,6 +139,13 @@ def test_heaviest_first_query_order_changes_nothing(small):
                       gpu.autocomplete_batch(blob=qb2, offs=qo2, limit=6))
     for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # ... and so must the tokeniser as a launch of its own (sg_terms_kernel: the default for batches of >= 2048 queries,
+    # i.e. what ran above) against the search kernel tokenising each query itself
+    gpu.tune(SG_PRETOK=0)
+    fused = (gpu.suggest_batch(blob=qb2, offs=qo2, metric="cosine", similarity=0.45, k=7), gpu.autocomplete_batch(blob=qb2, offs=qo2, limit=6))
+    gpu.tune(SG_PRETOK=2048)
+    for a, b in zip(fused[0] + fused[1], out[1][0] + out[1][1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
     want = list(ora.suggest_batch(qb2, qo2, "cosine", 0.45, 7)[:3])
     assert_same(out[1][0], want)                     # (query 4242: 300 runes, past the wavefront kernel's 144 — the long-query kernel's)
 

@@ -59,6 +59,8 @@ def make_trial(seed, scale=1):
         queries += [d[:60] + rng.choice(syms) + d[61:] for d in long_docs[:4]]
         if rng.random() < 0.5:
             searches.append((rng.choice(["jaccard", "cosine", "dice"]), rng.choice([0.2, 0.5, 0.8]), rng.choice([1500, 3000])))
+    # (drawn after everything else, as above) the tokeniser as a launch of its own — sg_terms_kernel — for batches of >= n queries
+    env["SG_PRETOK"] = rng.choice(["0", "1", "1", "2048"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
