@@ -371,7 +371,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                     "effective_* = algorithmic (ScanCount-volume, SURVEY.md 8d) bytes / the same time: list skipping and the compressed "
                     "posting store read less than that volume, so it may exceed the peak and is not a bandwidth. "
                     "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
-                    "queries and the two query-ordering launches (~10 us) before them"}
+                    "queries, the tokeniser launch (sg_terms_kernel) and the two query-ordering launches (~10 us) before it"}
     rec = {
         "value": total_q / elapsed,
         "unit": "queries/s",
@@ -579,14 +579,14 @@ def _live_traffic(args, w, log):
                     continue
                 if "sg_search_kernel_t<false, false," in row["Kernel_Name"]:
                     main_k.append(float(row["Counter_Value"]))
-                elif "sg_search_kernel_t<true, false," in row["Kernel_Name"]:
-                    parts_k.append(float(row["Counter_Value"]))
+                elif "sg_search_kernel_t<true, false," in row["Kernel_Name"] or "sg_terms_kernel" in row["Kernel_Name"]:
+                    parts_k.append(float(row["Counter_Value"]))      # (the other launches of a call: split queries' parts, the tokeniser)
         if not main_k:
             return None, "no FETCH_SIZE rows for the search kernel in the child's counter CSV"
         kb = sum(main_k) / len(main_k) + (sum(parts_k) / len(main_k) if parts_k else 0.0)
         log("[%s] live PMC pass: FETCH_SIZE %.6g KB per launch over %d launches (%.0fs)" % (w["name"], kb, len(main_k), time.time() - t0))
         return kb * 1024 * 2, ("live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass of this run, %d launches of this workload "
-                               "(search + parts kernels): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (len(main_k), kb))
+                               "(search + parts + tokeniser kernels): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (len(main_k), kb))
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
         return None, "live PMC pass failed: %r" % (exc,)
     finally:

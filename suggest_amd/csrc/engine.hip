@@ -41,6 +41,8 @@ namespace sg {
 #define SG_TILE_MAX 64     // segments per tile (one lane each)
 #define SG_UNROLL 4        // 16-byte loads in flight per lane
 #define SG_PPC 7           // postings per 16-byte chunk of the packed store: {u32 first x, 6 x u16 gaps} (packed_store.inc)
+#define SG_X_MASK 0x1FFFFFFFu   // first word of a chunk: x of its first posting | (postings in the chunk - 1) << 29
+#define SG_PAD_GAP 41u          // gap of the padding slots behind a chunk's last posting (packed_store.inc)
 #define SG_SUB 2           // rows counted per LDS round trip: SG_SUB * SG_PPC = 14 atomics issued, one wait
 #define SG_EPOCHS 4           // group passes whose candidates may wait in the queue together (ring of their streamed-list masks + docID ranges)
 #define SG_EPOCH_WORDS 6
@@ -705,13 +707,16 @@ typedef uint32_t u32x8v __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 static_assert(SG_UNROLL == 4 && SG_SUB == 2 && SG_SUB * SG_PPC <= 16, "u32x16 below holds SG_SUB rows x SG_PPC postings");
 
-// The SG_PPC postings of one packed chunk: first x, then six 16-bit gaps (a gap of 0 repeats the previous posting: padding).
+// The SG_PPC slots of one packed chunk: first x, then six 16-bit gaps.  Returns how many of them are postings (the top
+// three bits of the first word); the slots behind them are padding with gaps of SG_PAD_GAP — phantom numbers that no consumer but
+// the lossy counters of the stream may take for postings.
 template <class V>
-__device__ __forceinline__ void decode_chunk(const uint4& v, V& p, int at) {
-  p[at] = v.x;
+__device__ __forceinline__ uint32_t decode_chunk(const uint4& v, V& p, int at) {
+  p[at] = v.x & SG_X_MASK;
   p[at + 1] = p[at] + (v.y & 0xFFFFu); p[at + 2] = p[at + 1] + (v.y >> 16);
   p[at + 3] = p[at + 2] + (v.z & 0xFFFFu); p[at + 4] = p[at + 3] + (v.z >> 16);
   p[at + 5] = p[at + 4] + (v.w & 0xFFFFu); p[at + 6] = p[at + 5] + (v.w >> 16);
+  return (v.x >> 29) + 1u;
 }
 
 // Counts SG_SUB rows (a row = up to 64 consecutive 16-byte chunks of ONE posting list, one chunk = SG_PPC postings per
@@ -735,21 +740,24 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_SUB], const u
   uint32_t old[SG_SUB * SG_PPC];
 #pragma unroll
   for (int u = 0; u < SG_SUB; u++) {
-    // the six gaps; a zero gap repeats the previous posting (the padding of a list's last chunk, or of a chunk cut short by a
-    // gap above 65 535): it adds NOTHING — counted, the copies would pre-load a bucket at every list end with up to six
-    // phantom postings and flag whatever else falls into it (measured: 3x the flagged postings at thresholds of 6..11)
-    const uint32_t g[SG_PPC] = {1u, v[u].y & 0xFFFFu, v[u].y >> 16, v[u].z & 0xFFFFu, v[u].z >> 16, v[u].w & 0xFFFFu, v[u].w >> 16};
+    // the six gaps.  EVERY slot adds 1: the padding of a chunk (the end of a list, or a chunk cut short by a gap above
+    // 65 535) has gaps of SG_PAD_GAP, i.e. its slots are phantom postings of numbers behind the chunk's last one — each in a
+    // bucket of its own, a per cent or two of noise in counters that are upper bounds anyway (they overcount, never
+    // undercount; what enters the candidate queue is checked against the chunk's posting count, flagged()).  Padding as
+    // repeats of the last posting (gaps of 0, rounds 1-3) needed an increment of its own per slot — min(gap, live), one
+    // VALU instruction in seven — because counted, the copies pre-loaded one bucket with up to six postings.
+    const uint32_t g[SG_PPC] = {0u, v[u].y & 0xFFFFu, v[u].y >> 16, v[u].z & 0xFFFFu, v[u].z >> 16, v[u].w & 0xFFFFu, v[u].w >> 16};
     // Lanes past the end of the list hold copies of its last chunk; aimed at the real counters they would
-    // all hit the same words (address conflicts serialise LDS atomics).  They add 0 to a lane-private
-    // dummy word instead: per ROW two selects, per posting still one v_and_or_b32.
+    // count it again.  They add to a lane-private dummy word instead (never read): per ROW two selects, per
+    // posting still one v_and_or_b32.
     const uint32_t am = live[u] ? amask : 0u;
     const uint32_t cb = live[u] ? cbase : dummy;
-    uint32_t d = v[u].x;
+    uint32_t d = v[u].x & SG_X_MASK;
 #pragma unroll
     for (int e = 0; e < SG_PPC; e++) {
       if (e) d += g[e];
       pp[u * SG_PPC + e] = d;
-      const uint32_t inc = min(g[e], live[u]);                 // 1 for a posting of a live lane, else 0
+      const uint32_t inc = 1u;
       lds_u32* w = counter_word(d, am, cb);
       if (U8) {
         // byte lane = docID & 3: the shift amount is (d << 3) mod 32 — the hardware shifters and v_bfe use
@@ -1103,12 +1111,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           if (nch) {                                             // the last chunk that begins at or before x, then its postings
             const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
             uint32_t lo = 0, hi = nch;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[(uint64_t)mid * 4] <= x) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & SG_X_MASK) <= x) lo = mid + 1; else hi = mid; }
             if (lo) {
               u32x8v pc;
-              decode_chunk(post4[s0 + lo - 1u], pc, 0);
+              const uint32_t np = decode_chunk(post4[s0 + lo - 1u], pc, 0);
 #pragma unroll
-              for (int e = 0; e < SG_PPC; e++) found |= pc[e] == x;
+              for (int e = 0; e < SG_PPC; e++) found |= (uint32_t)e < np && pc[e] == x;
             }
           }
         }
@@ -1414,7 +1422,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       uint32_t ep_tag = 0, q0 = qn;                             // (set at the top of every pass)
       // slow path of one counted batch whose row descriptors are rows4[0..3]: the flagged postings go to the queue
       // (per posting slot one ballot + a prefix count: the lanes store their own postings)
-      auto flagged = [&](const u32x16& vv, const uint32_t (&live)[SG_SUB], const u32x16& was, uint32_t mx, uint32_t row0, uint32_t Tm1) {
+      auto flagged = [&](const u32x16& vv, const uint32_t (&live)[SG_SUB], const u32x16& was, uint32_t mx, uint32_t row0, uint32_t Tm1,
+                         uint32_t last0, uint32_t last1) {   // last0/1: slot of the last posting in the lane's chunk of either row
         // a u8 counter about to wrap would carry into its neighbour and — worse — undercount its own bucket.  Every
         // increment returns the value it found, and a counter passes through every value on its way up, so "some
         // posting found >= 250" is seen before any wrap (reading the counter afterwards is not: identical lists of a
@@ -1430,8 +1439,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           const int ue = __builtin_ctz(any_fl);
           any_fl &= any_fl - 1u;
           const int e = ue >= SG_PPC ? ue - SG_PPC : ue;
-          // (zero gaps repeat a posting — the padding of a chunk: one posting, not several)
-          const bool mine = (ue >= SG_PPC ? live[1] : live[0]) && was[ue] >= Tm1 && !(e && vv[ue] == vv[ue ? ue - 1 : 0]);
+          // (the slots behind a chunk's last posting are padding: phantom numbers, never candidates)
+          const bool mine = (ue >= SG_PPC ? live[1] : live[0]) && was[ue] >= Tm1 && (uint32_t)e <= (ue >= SG_PPC ? last1 : last0);
           const uint64_t m = ballot(mine);
           if (!m) continue;
           const uint32_t cnt_f = popc64(m);
@@ -1517,7 +1526,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
               for (int i = 0; i < 8; i++) {
                 pos[i] = min(lo + ((hi - lo) * (uint32_t)(i + 1)) / 9u, n ? n - 1u : 0u);
-                val[i] = n ? p[(uint64_t)pos[i] * 4] : 0xFFFFFFFFu;
+                val[i] = n ? p[(uint64_t)pos[i] * 4] & SG_X_MASK : 0xFFFFFFFFu;
               }
               uint32_t nlo = lo, nhi = hi;
 #pragma unroll
@@ -1607,6 +1616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) :: "memory");
 #pragma unroll
             for (int h = 0; h < SG_UNROLL / SG_SUB; h++) {     // SG_SUB rows = 14 postings per LDS round trip
+              if (h && row0 + (uint32_t)(SG_SUB * h) >= wn) break;   // the window's last batch: both rows of this half are dead rows
               const uint4 pv[SG_SUB] = {make_uint4(qv[2 * h].x, qv[2 * h].y, qv[2 * h].z, qv[2 * h].w),
                                         make_uint4(qv[2 * h + 1].x, qv[2 * h + 1].y, qv[2 * h + 1].z, qv[2 * h + 1].w)};
               const uint32_t sl[SG_SUB] = {pl[2 * h], pl[2 * h + 1]};
@@ -1616,7 +1626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
               if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x));
               else any = u8 ? count_rows<true>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx) : count_rows<false>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx);
               DBG_COUNT(1, 1)
-              if (any) { PH(5) flagged(pp, sl, was, mx, row0 + (uint32_t)(SG_SUB * h), Tm1); PH(6) }
+              if (any) { PH(5) flagged(pp, sl, was, mx, row0 + (uint32_t)(SG_SUB * h), Tm1, pv[0].x >> 29, pv[1].x >> 29); PH(6) }
             }
           };
           // fetches are unconditional (rows past the last are dead rows: they load chunk 0): every process() has the four
@@ -1659,13 +1669,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < n) v = post4[s + c];
             u32x8v pc;
-            decode_chunk(v, pc, 0);
+            const uint32_t np = decode_chunk(v, pc, 0);
 #pragma nounroll
             for (int e = 0; e < SG_PPC; e++) {
               const uint32_t d = pc[e];
-              const uint32_t dprev = pc[e ? e - 1 : 0];
               bool flag = false;
-              if (c < n && !(e > 0 && d == dprev)) {
+              if (c < n && (uint32_t)e < np) {
                 const uint32_t bk = d & ((1u << lg) - 1u);
                 const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
                 flag = now >= (uint32_t)Teff;
@@ -1975,9 +1984,9 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
       const uint32_t c0 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], c1 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u];
       for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += 64) {
         u32x8v pc;
-        decode_chunk(((const uint4*)ix.postings)[c], pc, 0);
+        const uint32_t np = decode_chunk(((const uint4*)ix.postings)[c], pc, 0);
 #pragma unroll
-        for (int e = 0; e < SG_PPC; e++) if (e == 0 || pc[e] != pc[e - 1]) atomicAdd(cnt + (pc[e] - x0), 1u);
+        for (int e = 0; e < SG_PPC; e++) if ((uint32_t)e < np) atomicAdd(cnt + (pc[e] - x0), 1u);
       }
     }
     __threadfence();
@@ -2021,8 +2030,8 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
                 {
                   const uint32_t* p = ix.postings + (uint64_t)c0 * 4;
                   uint32_t lo = 0, hi = nch;
-                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p[(uint64_t)mid * 4] <= x) lo = mid + 1; else hi = mid; }
-                  if (lo) { u32x8v pc; decode_chunk(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC; e++) has |= pc[e] == x; }
+                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & SG_X_MASK) <= x) lo = mid + 1; else hi = mid; }
+                  if (lo) { u32x8v pc; const uint32_t np = decode_chunk(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC; e++) has |= (uint32_t)e < np && pc[e] == x; }
                 }
                 const uint32_t ts = t * (uint32_t)S + (uint32_t)B;
                 len = ix.list_len[ts];
