@@ -697,8 +697,16 @@ __device__ const uint8_t kBucketsPer16Postings[8][33] = {
     {255, 255, 255, 202, 57, 28, 17, 12, 9, 7, 6, 5, 4, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1},
     {255, 255, 255, 108, 37, 20, 13, 9, 7, 6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1},
     {255, 255, 255, 60, 25, 14, 10, 7, 6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1}};
-__device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T, uint32_t level) {
-  const uint32_t m16 = kBucketsPer16Postings[level][T < 0 ? 0 : (T > 32 ? 32 : T)];
+// The launch's row of the table lives in a register — lane t holds m16[level][min(t, 32)] — because the lookups sit on
+// the critical path of every group's setup (group sizes, list skipping, counter geometry: two dependent lookups per group)
+// and a load from the table in memory is a VMEM round trip under a saturated memory system: ~1 us each, a fifth of a
+// headline query's time.  Uniform T: v_readlane; T per lane: ds_bpermute.
+__device__ __forceinline__ uint32_t buckets_needed(uint32_t postings, int T, uint32_t m16_lane) {       // T uniform
+  const uint32_t m16 = readlane(m16_lane, T < 0 ? 0 : (T > 32 ? 32 : T));
+  return (postings * m16) >> 4;
+}
+__device__ __forceinline__ uint32_t buckets_needed_lane(uint32_t postings, int T, uint32_t m16_lane) {  // T differs by lane
+  const uint32_t m16 = (uint32_t)__builtin_amdgcn_ds_bpermute((T < 0 ? 0 : (T > 32 ? 32 : T)) << 2, (int)m16_lane);
   return (postings * m16) >> 4;
 }
 
@@ -864,6 +872,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   uint64_t* keys = (uint64_t*)(cnt + SG_MAX_RUNES);
 
   const uint32_t k = a.k;
+  const uint32_t m16_lane = kBucketsPer16Postings[a.filter_level][min(lane, 32)];   // (see buckets_needed)
   PH_DECL
   DBG_DECL
 
@@ -1325,11 +1334,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     // buckets a segment needs once its longest lists are skipped down to a.t_floor (estimate: equal
     // lengths), computed by the segment's own lane; groups are then cut by accumulating these.
-    uint32_t seg_need = 0;
+    uint32_t seg_need = 0, need_p = 0;
+    int need_T = 0;
     if (seg_valid) {
       const int k = (seg_T > a.t_floor && !DBG_SKIP(8u)) ? min(seg_T - a.t_floor, A - 1) : 0;
       const uint32_t rem = seg_tot - (uint32_t)((float)seg_tot * (float)k * (1.0f / (float)A));
-      seg_need = max(1u, buckets_needed(rem * SG_PPC, seg_T - k, a.filter_level));
+      need_T = seg_T - k; need_p = rem * SG_PPC;
+    }
+    {   // (every lane takes part in the permute: the table row sits in lanes 0..32)
+      const uint32_t bn = buckets_needed_lane(need_p, need_T, m16_lane);
+      if (seg_valid) seg_need = max(1u, bn);
     }
 
     // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
@@ -1398,7 +1412,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
           const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
           const int k_skip = (int)(popc64(pick0) + popc64(pick1));
-          if (buckets_needed((L - skipped) * SG_PPC, Tmin - k_skip, a.filter_level) <= max_buckets) {
+          if (buckets_needed((L - skipped) * SG_PPC, Tmin - k_skip, m16_lane) <= max_buckets) {
             skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
           }
         }
@@ -1406,7 +1420,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = buckets_needed(Leff * SG_PPC, Teff, a.filter_level);
+      const uint32_t need = buckets_needed(Leff * SG_PPC, Teff, m16_lane);
       bool u8 = need > cnt_words && Teff <= 200;
       uint32_t lg = 8;
       {

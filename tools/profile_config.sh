@@ -32,14 +32,14 @@ for p in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
 parts = []
 for p in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(p)):
-        if "sg_search_kernel_t<true, false," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+        if ("sg_search_kernel_t<true, false," in r["Kernel_Name"] or "sg_terms_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
             parts.append(float(r["Counter_Value"]))
 out = {"config": cfg, "tag": tag, "dispatches": len(vals)}
 if vals:
     kb = sum(vals) / len(vals) + (sum(parts) / len(vals) if parts else 0.0)
     out["fetch_size_kb_per_launch"] = kb
     out["bytes_per_launch"] = kb * 1024 * 2
-    out["source"] = "rocprofv3 --pmc FETCH_SIZE --kernel-trace (tools/profile_config.sh %s %s): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md); search + parts kernels, %d launches" % (tag, cfg, kb, len(vals))
+    out["source"] = "rocprofv3 --pmc FETCH_SIZE --kernel-trace (tools/profile_config.sh %s %s): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md); search + parts + tokeniser kernels, %d launches" % (tag, cfg, kb, len(vals))
 try:
     b = json.loads([l for l in open(bench) if l.startswith("{")][-1])
     out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
