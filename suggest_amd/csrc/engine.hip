@@ -1569,8 +1569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         er[4] = lo_doc; er[5] = hi_doc;
       }
       for (int attempt = 0; attempt < 2; attempt++) {
-        const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);
-        for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
+        const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);     // (cleared below, behind the first row loads)
         const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
@@ -1647,6 +1646,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           // loads of the following batch behind its own
           const uint32_t n_batches = (wn + SG_UNROLL - 1) / SG_UNROLL;
           fetch(v, live);
+          if (w0 == 0u) {       // the counters are cleared while the group's first rows are on their way (one wavefront: its
+            // LDS instructions execute in order, the stores are ahead of the first atomics; a barrier here would carry a
+            // fence that waits for the row loads)
+            for (uint32_t w = lane * 4; w < words; w += 256) *(uint4*)(cnt + w) = make_uint4(0, 0, 0, 0);
+            asm volatile("" ::: "memory");
+          }
           for (uint32_t bi = 0; bi < n_batches; bi += 2) {
             fetch(vn, liven);
             process(v, live, bi * SG_UNROLL);
