@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   uint32_t* cnt = smem;
   const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32*)cnt;   // LDS byte address of the counters (aligned to their size)
   uint32_t* term = cnt + cnt_words;
-  uint32_t* rows = term + SG_MAX_A;
+  uint32_t* rows = term + SG_MAX_A;                 // (moved up against the query's last term once A is known: see wt_max)
   const uint32_t cq_cap = a.cq_cap;                                  // (what the LDS budget leaves: sg_queue_cap, set by the host —
                                                                      //  computed here, the LDS pointers behind the queue cost registers)
   uint32_t* cq_doc = rows + L::rows_cap;            // candidate queue: docs whose bucket reached the flag threshold ...
@@ -972,7 +972,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
   const uint4* __restrict__ post4 = (const uint4*)ix.postings;
   const int a_rounds = (A + 63) >> 6;                          // 1 or 2 (A <= SG_MAX_A = 128)
-  const int wt_max = min(SG_TILE_MAX, (int)L::rows_cap / A - 1);   // A <= 128 -> >= 7
+  // The term ids take A of their SG_MAX_A words; the rest joins the segment table behind them: a query of 20 terms gets 556
+  // words instead of 448 (slim layout) and its whole window — 23 segments at Jaccard 0.5 — becomes ONE tile instead of two
+  // (one fetch of the seg_off rows, one round of statistics and thresholds, groups that merge across the former seam).
+  const uint32_t term_words = ((uint32_t)A + 3u) & ~3u;
+  rows = term + term_words;
+  const int wt_max = min(SG_TILE_MAX, (int)((L::rows_cap + SG_MAX_A - term_words) / (uint32_t)A) - 1);   // A <= 128 -> >= 3
   const uint32_t max_buckets = cnt_words * 4u;                 // u8 mode
 
   uint32_t pushed = 0;                                         // parts of this query queued for the second launch
