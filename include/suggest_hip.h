@@ -66,8 +66,8 @@ int sg_index_build(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, c
 
 /* Same index, built on the GPU `device`: documents are tokenised by the kernel-side tokenizer, terms
  * interned in a device hash table, postings radix-sorted and laid out as the same CSR — array for array identical to
- * sg_index_build's (sg_index_digest).  Fails with SG_E_UNSUPPORTED when a document has more than 128
- * n-grams (use sg_index_build).  The index still has to be uploaded with sg_index_upload. */
+ * sg_index_build's (sg_index_digest).  Fails with SG_E_UNSUPPORTED when a document has more than 65 536 bytes or the
+ * dictionary 2^26 documents or more (use sg_index_build).  The index still has to be uploaded with sg_index_upload. */
 int sg_index_build_device(const uint8_t* utf8, const uint64_t* offs, uint32_t n_docs, const sg_desc* desc, int device,
                           sg_index** out);
 
@@ -85,7 +85,8 @@ int sg_index_load_reference(const char* hd_path, const char* dl_path, const sg_d
 /* Copies the CSR index into the HBM of `device` (one replica per GPU; per-process).  The first upload makes the primary
  * replica (the one sg_suggest_batch / sg_autocomplete_batch run on); uploading to a device that already holds a replica is
  * a no-op.  A device-built index (sg_index_build_device) whose first upload goes to the building device keeps the posting
- * store where the build left it (no D2H + H2D round trip).  Safe to call concurrently. */
+ * store where the build left it (no D2H + H2D round trip).  Safe to call concurrently.  SG_E_UNSUPPORTED: the packed
+ * posting store numbers documents below 2^29 (shard larger dictionaries by docID range: sg_index_build_ex). */
 int sg_index_upload(sg_index* index, int device);
 
 /* Multi-GPU (BASELINE north_star: "query batches shard naturally across the 8 GPUs of one node"): ONE host
@@ -235,7 +236,7 @@ int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, 
 int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* out);
 
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
- * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
+ * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_PRETOK, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */
 int sg_index_tune(sg_index* index, const char* knob, int value);
 
 /* Tokens of `text` as the index sees them, one packed 64-bit term key each (DESIGN.md §Term keys);
