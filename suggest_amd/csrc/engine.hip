@@ -979,6 +979,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   rows = term + term_words;
   const int wt_max = min(SG_TILE_MAX, (int)((L::rows_cap + SG_MAX_A - term_words) / (uint32_t)A) - 1);   // A <= 128 -> >= 3
   const uint32_t max_buckets = cnt_words * 4u;                 // u8 mode
+  // A dictionary with no more documents than the wavefront has u8 counters (the reference's own test dictionaries; 8 192
+  // at the default size): every document gets a counter of its own.  Nothing is skipped and nothing is flagged on the way
+  // — the counters are read once after the group's stream, and what reaches the lowest threshold of the group is verified
+  // as usual (the padding's phantom postings make the counts upper bounds even here).  The lossy scheme on such a
+  // dictionary queued every match once per streamed list behind its T'-th and verified ~15 candidates per result (cars:
+  // verification 43 % of a wavefront's time, the flagged path another 10 %).
+  const bool tiny = ix.n_docs <= max_buckets;
 
   uint32_t pushed = 0;                                         // parts of this query queued for the second launch
   for (int tb = b_min; tb <= b_max; tb += wt_max) {
@@ -1348,7 +1355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     {   // (every lane takes part in the permute: the table row sits in lanes 0..32)
       const uint32_t bn = buckets_needed_lane(need_p, need_T, m16_lane);
-      if (seg_valid) seg_need = max(1u, bn);
+      if (seg_valid) seg_need = tiny ? 0u : max(1u, bn);       // (tiny: every run of valid segments is one group)
     }
 
     // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
@@ -1395,7 +1402,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       uint64_t skip_m[2] = {0, 0};
       int Teff = Tmin;
       uint32_t Leff = L;
-      if (Tmin > a.t_floor && !DBG_SKIP(8u)) {
+      if (Tmin > a.t_floor && !DBG_SKIP(8u) && !tiny) {
         const uint32_t n_ne = popc64(ballot(ln_r[0] != 0)) + (a_rounds > 1 ? popc64(ballot(ln_r[1] != 0)) : 0u);
         const uint32_t th[4] = {L * 2u, L + (L >> 2), L, L >> 1};
         uint64_t pick0 = 0, pick1 = 0;
@@ -1425,8 +1432,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = buckets_needed(Leff * SG_PPC, Teff, m16_lane);
+      const uint32_t need = tiny ? max_buckets : buckets_needed(Leff * SG_PPC, Teff, m16_lane);
       bool u8 = need > cnt_words && Teff <= 200;
+      bool exact = tiny && u8;                                   // (the u32 re-run of a saturated group is lossy again)
+      // the group's documents are the numbers [x_lo, x_hi): what the read-out below may take for candidates
+      const uint32_t x_lo = tiny ? ix.seg_base[tb + g0] : 0u, x_hi = tiny ? ix.seg_base[tb + g1 + 1] : 0u;
       uint32_t lg = 8;
       {
         const uint32_t lg_max = u8 ? a.log2_cnt + 2 : a.log2_cnt;
@@ -1575,7 +1585,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       for (int attempt = 0; attempt < 2; attempt++) {
         const uint32_t words = u8 ? (1u << lg) >> 2 : (1u << lg);     // (cleared below, behind the first row loads)
-        const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = (uint32_t)Teff - 1u;
+        // (exact: no posting is flagged on the way — only the watch for a u8 counter about to wrap stays on)
+        const uint32_t amask = u8 ? (((1u << lg) - 1u) & ~3u) : (((1u << lg) - 1u) << 2), Tm1 = exact ? 249u : (uint32_t)Teff - 1u;
         __syncthreads();
         PH(3)
         // Rows of 64 chunks, list after list.  Lane i knows how many rows its list has (nr) and the running
@@ -1671,37 +1682,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // A u8 counter came close to wrapping: the group is counted again with u32 counters (nothing of it has reached
         // the top-k yet: its candidates are only queued)
         qn = q0; overflow = false;
-        u8 = false; saturated = false;
+        u8 = false; saturated = false; exact = false;
         lg = min(lg, a.log2_cnt);
         __syncthreads();
       }
-      if (overflow) {
+      if (overflow || exact) {
+        // exact: the read-out — lane <-> counter word, its four bytes are four documents; queued as met "behind every list"
+        // (position 255: never late).
         // More flagged postings than the queue holds (dictionaries of near-duplicates: dozens of matches per query, each
         // flagged in every list from its T'-th on).  The lists are walked again against the FINAL counters — a superset of
         // what the stream flagged, counts only grow — and the queue is emptied whenever it fills; the verdict rule (emit at
         // the last streamed list holding the doc) keeps every document single.
         qn = q0;                                                 // this pass's entries go (what earlier ones queued stays)
         int lists_before = 0;
-        for (int i = 0; i < A; i++) {
-          const int r = (i >> 6) & 1, li = i & 63;
-          if (!(((r ? str_m[1] : str_m[0]) >> li) & 1ull)) continue;
-          // a document in >= Teff streamed lists has its LAST occurrence in the Teff-th streamed list or later
-          if (lists_before++ < Teff - 1) continue;
-          const uint32_t s = readlane(r ? ls_r[1] : ls_r[0], li), n = readlane(r ? ln_r[1] : ln_r[0], li);
+        const int n_outer = exact ? 1 : A;
+        for (int i = 0; i < n_outer; i++) {
+          uint32_t s = x_lo >> 2, n = ((x_hi + 3u) >> 2) - (x_lo >> 2);      // exact: the counter words of the group's documents
+          if (!exact) {
+            const int r = (i >> 6) & 1, li = i & 63;
+            if (!(((r ? str_m[1] : str_m[0]) >> li) & 1ull)) continue;
+            // a document in >= Teff streamed lists has its LAST occurrence in the Teff-th streamed list or later
+            if (lists_before++ < Teff - 1) continue;
+            s = readlane(r ? ls_r[1] : ls_r[0], li); n = readlane(r ? ln_r[1] : ln_r[0], li);
+          }
           for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t c = c0 + lane;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < n) v = post4[s + c];
             u32x8v pc;
-            const uint32_t np = decode_chunk(v, pc, 0);
+            uint32_t np = 4u;
+            if (exact) {
+              const uint32_t word = c < n ? cnt[s + c] : 0u;
+              pc[0] = word & 0xFFu; pc[1] = (word >> 8) & 0xFFu; pc[2] = (word >> 16) & 0xFFu; pc[3] = word >> 24;
+              pc[4] = pc[5] = pc[6] = 0u;
+            } else {
+              uint4 v = make_uint4(0, 0, 0, 0);
+              if (c < n) v = post4[s + c];
+              np = decode_chunk(v, pc, 0);
+            }
 #pragma nounroll
             for (int e = 0; e < SG_PPC; e++) {
-              const uint32_t d = pc[e];
+              const uint32_t d = exact ? (s + c) * 4u + (uint32_t)e : pc[e];
               bool flag = false;
               if (c < n && (uint32_t)e < np) {
-                const uint32_t bk = d & ((1u << lg) - 1u);
-                const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
-                flag = now >= (uint32_t)Teff;
+                if (exact) flag = pc[e] >= (uint32_t)Teff && d >= x_lo && d < x_hi;
+                else {
+                  const uint32_t bk = d & ((1u << lg) - 1u);
+                  const uint32_t now = u8 ? ((cnt[bk >> 2] >> ((bk & 3u) << 3)) & 0xFFu) : cnt[(d >> 2) & ((1u << lg) - 1u)];
+                  flag = now >= (uint32_t)Teff;
+                }
               }
               const uint64_t m_all = ballot(flag);
               if (!m_all) continue;
@@ -1714,7 +1741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 DBG_COUNT(3, cnt_f)
                 if (qn + cnt_f > cq_cap) flush_queue();
                 const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (flag && ((m >> lane) & 1ull)) { cq_doc[pos] = d; cq_jj[pos] = (uint32_t)i | ep_tag; }
+                if (flag && ((m >> lane) & 1ull)) { cq_doc[pos] = d; cq_jj[pos] = (exact ? 0xFFu : (uint32_t)i) | ep_tag; }
                 qn += cnt_f;
               }
             }

@@ -224,6 +224,35 @@ def test_random_small_dictionaries_property():
         assert np.array_equal(ids[valid], oi[valid]), (trial, desc)
 
 
+@pytest.mark.parametrize("n_docs", [8191, 8192, 8193, 16384])
+def test_one_counter_per_document_on_dictionaries_below_the_counter_count(n_docs):
+    """A dictionary with at most as many documents as a wavefront has u8 counters (8 192 at the default size) is searched
+    without list skipping and without flags on the way: the counters are read out after a group's stream and what
+    reaches the threshold is verified (engine.hip, `tiny`).  Sizes on both sides of the switch, near-duplicate families
+    (many matches per query, ties), low and high thresholds, the tightening instantiation, autocomplete; SG_LOG2_CNT=12
+    moves the switch to 16 384."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    blob, offs = synth.make_dict(n_docs, seed=5, families=3)
+    desc = dict(synth.DESCRIPTION)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+    qb, qo = synth.make_queries(3000, blob, offs, seed=6)
+    queries = synth.unpack(qb, qo)
+    for log2_cnt in ((11, 12) if n_docs > 8192 else (11,)):
+        for tighten in (0, 1):
+            gpu.tune(SG_LOG2_CNT=log2_cnt, SG_TIGHTEN=tighten)
+            for metric, a, k in (("jaccard", 0.5, 10), ("cosine", 0.2, 5), ("dice", 0.8, 3), ("overlap", 0.4, 70)):
+                assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=a, k=k),
+                            ora.suggest_batch(qb, qo, metric, a, k), queries)
+    pre = [q[:5] for q in queries[:1500]]
+    pb, po = oracle.pack_strings(pre)
+    ids, cnt = gpu.autocomplete_batch(blob=pb, offs=po, limit=9)
+    oi, oc, _ = ora.autocomplete_batch(pb, po, 9)
+    assert np.array_equal(cnt, oc)
+    valid = np.arange(9)[None, :] < np.minimum(cnt, 9)[:, None]
+    assert np.array_equal(ids[valid], oi[valid])
+
+
 def ora_tokens_ok(doc, q, wrap, pad, alpha):
     return len(oracle.OracleIndex([doc], ngram_size=q, wrap=wrap, pad=pad, alphabet=alpha).tokenize(doc)) > 0
 
