@@ -996,10 +996,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // (e / stride by a 20-bit reciprocal: exact for e * stride < 2^20 — e < 128 * 65 — and two full-rate instructions
     //  where the compiler's unsigned division is twenty)
     const uint32_t rcp = (1u << 20) / stride + 1u;
-    for (uint32_t e = lane; e < (uint32_t)A * stride; e += 64) {
-      const uint32_t i = __umul24(e, rcp) >> 20, w = e - __umul24(i, stride);
-      const uint32_t t = term[i];
-      rows[e] = t == kNoTerm ? 0u : ix.seg_off[(uint64_t)t * (uint32_t)(S + 1) + (uint32_t)tb + w];
+    // (eight loads in flight per lane: as a plain loop — load, wait, store to LDS — the table of a 20-term query was nine
+    //  dependent memory round trips, a fifth of a small-dictionary query's time)
+    const uint32_t n_e = (uint32_t)A * stride;
+    for (uint32_t e0 = lane; e0 < n_e; e0 += 64u * 8u) {
+      uint32_t got[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++) {
+        const uint32_t e = e0 + 64u * u;
+        got[u] = 0u;
+        if (e < n_e) {
+          const uint32_t i = __umul24(e, rcp) >> 20, w = e - __umul24(i, stride);
+          const uint32_t t = term[i];
+          if (t != kNoTerm) got[u] = ix.seg_off[(uint64_t)t * (uint32_t)(S + 1) + (uint32_t)tb + w];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++) {
+        const uint32_t e = e0 + 64u * u;
+        if (e < n_e) rows[e] = got[u];
+      }
     }
     cnt[lane] = 0u; cnt[64 + lane] = 0u;                          // (the counters are idle between groups: scratch of the statistics)
     __syncthreads();
