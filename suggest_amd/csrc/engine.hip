@@ -812,6 +812,18 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_SUB], const u
 #define PH_FLUSH
 #endif
 
+// minimum over the wave (DPP network, as wave_scan_incl)
+__device__ __forceinline__ int wave_min_i32(int v) {
+  const int I = 0x7FFFFFFF;
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x111, 0xf, 0xf, false));   // row_shr:1 (lanes without a source keep I)
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x112, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x114, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x118, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return (int)readlane((uint32_t)v, 63);
+}
+
 // ------------------------------------------------------------------------------------------
 // The fused search kernel.  grid = n_q workgroups of one wavefront; dynamic LDS per wave:
 //   cnt[1<<log2_cnt] u32 (tokeniser scratch aliases it) | term | rows | cand, candw | topk
@@ -1374,6 +1386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       if (seg_valid) seg_need = tiny ? 0u : max(1u, bn);       // (tiny: every run of valid segments is one group)
     }
 
+    const uint32_t P_need = wave_scan_incl(seg_need, lane), P_tot = wave_scan_incl(seg_valid ? seg_tot : 0u, lane);
     // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
     const bool tightening = kTight && !kLM && !a.autocomplete;
     auto tightened_against = [&]() -> uint64_t { return (uint64_t)tile_state[0] | ((uint64_t)tile_state[1] << 32); };
@@ -1387,18 +1400,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const uint64_t rest = (vmask >> wnext) << wnext;
       if (!rest) break;
       const int g0 = __builtin_ctzll(rest);
-      int g1 = g0;
-      uint32_t L = readlane(seg_tot, g0);                     // 16-byte chunks of the group
-      uint32_t need_acc = readlane(seg_need, g0);
-      int Tmin = (int)readlane((uint32_t)seg_T, g0);
-      // merge following valid segments while the counters still resolve the group
-      for (;;) {
-        const int nx = g1 + 1;
-        if (nx >= Wt || !((vmask >> nx) & 1)) break;
-        const uint32_t nn = readlane(seg_need, nx);
-        if (need_acc + nn > max_buckets) break;
-        need_acc += nn; L += readlane(seg_tot, nx); Tmin = min(Tmin, (int)readlane((uint32_t)seg_T, nx)); g1 = nx;
-      }
+      // merge following valid segments while the counters still resolve the group: the run of valid segments from g0 on,
+      // cut where the running sum of their bucket needs passes the counters (always at least g0 itself) — from the
+      // tile's prefix sums, a ballot and two bit scans (as a loop it was three v_readlane per segment, each feeding a
+      // scalar compare: 25 dependent rounds per query)
+      const uint32_t base_need = g0 ? readlane(P_need, g0 - 1) : 0u, base_tot = g0 ? readlane(P_tot, g0 - 1) : 0u;
+      const uint64_t inv = ~vmask >> g0;
+      const int run_len = inv ? __builtin_ctzll(inv) : 64 - g0;
+      const uint64_t unfit = ~(ballot(P_need - base_need <= max_buckets) >> g0);
+      const int fit_len = unfit ? __builtin_ctzll(unfit) : 64;
+      const int g1 = g0 + max(1, min(run_len, fit_len)) - 1;
+      const uint32_t L = readlane(P_tot, g1) - base_tot;      // 16-byte chunks of the group
+      const int Tmin = wave_min_i32((lane >= g0 && lane <= g1) ? seg_T : 0x7FFFFFFF);
       wnext = g1 + 1;
 
       // ---- the group's lists: list i = postings of term i over segments tb+g0 .. tb+g1;
