@@ -20,8 +20,24 @@ ap.add_argument("--topk", type=int, default=10)
 ap.add_argument("--ngram", type=int, default=3)
 ap.add_argument("--dict-variant", default="uniform")
 ap.add_argument("--golden", default=None, choices=[None, "cars", "words"], help="use the reference's cars / words dictionary instead")
+ap.add_argument("--autocomplete", type=int, default=0,
+                help="autocomplete mode: prefixes of this many letters (+ 0..2) over a vocabulary of --dict-size random words of 3..12 letters "
+                     "(the index of BASELINE config 5), limit = --topk")
 args = ap.parse_args()
-if args.golden:
+if args.autocomplete:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    rng = np.random.Generator(np.random.PCG64(7))
+    need = int(args.dict_size * 1.3) + 64
+    ln = rng.integers(3, 13, size=need)
+    chars = rng.integers(0, 26, size=(need, 12), dtype=np.uint8) + ord("a")
+    chars[np.arange(12)[None, :] >= ln[:, None]] = 0
+    words = [bytes(w) for w in np.unique(np.ascontiguousarray(chars).view("S12").ravel())[:args.dict_size]]
+    pick = rng.integers(0, len(words), size=args.queries)
+    extra = rng.integers(0, 3, size=args.queries)
+    qb, qo = oracle.pack_strings([words[int(i)][:args.autocomplete + int(e)] for i, e in zip(pick, extra)])
+    ix = NGramIndex(words, IndexDescription(ngram_size=3, wrap=("^", "$"), pad="$", alphabet=("english", "russian", "numbers", "$^'")))
+elif args.golden:
     import lzma
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
@@ -50,17 +66,22 @@ k, n_q = args.topk, args.queries
 d_q = torch.from_numpy(qb).to(dev); d_offs = torch.from_numpy(qo.view(np.int64)).to(dev)
 d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
+def run():
+    st = torch.cuda.current_stream().cuda_stream
+    if args.autocomplete:
+        ix.autocomplete_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, k, d_ids.data_ptr(), d_cnt.data_ptr(), stream=st)
+    else:
+        ix.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k, d_ids.data_ptr(), d_sc.data_ptr(),
+                                d_cnt.data_ptr(), stream=st)
 for it in range(3):
     prof.zero_()
     torch.cuda.synchronize()
-    ix.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k, d_ids.data_ptr(), d_sc.data_ptr(),
-                            d_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    run()
     torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for it in range(5):
-    ix.suggest_batch_device(d_q.data_ptr(), d_offs.data_ptr(), n_q, args.metric, args.similarity, k, d_ids.data_ptr(), d_sc.data_ptr(),
-                            d_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    run()
 e1.record(); torch.cuda.synchronize()
 print("SG_DEBUG_SKIP=%s kernel ms (instrumented build): %.3f" % (os.environ.get("SG_DEBUG_SKIP", "0"), e0.elapsed_time(e1) / 5))
 allp = prof.cpu().numpy().astype(np.float64).reshape(2, 4096, 8).sum(axis=1) / 6
