@@ -239,16 +239,30 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     alg_timed = float(np.mean([alg[i % n_b] for i in range(steps)]))       # algorithmic bytes per launch, timed launches
     t = torch.tensor([elapsed], dtype=torch.float64)
+    per_rank = None
     if world > 1:
+        every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, t)                               # (gloo: the ranks' own clocks around the same K steps)
+        rates = [n_q * steps / float(x.item()) for x in every]
+        per_rank = {"min": min(rates), "max": max(rates), "mean": float(np.mean(rates)), "unit": "queries/s",
+                    "kernel_ms_avg_rank0": float(np.mean(kernel_ms))}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    gather_ok = None
-    if world > 1:                       # untimed functional check of the optional result gather over RCCL
+    gather_ok, gather_ms = None, None
+    if world > 1:                       # functional check of the optional result gather over RCCL, and its cost per step (outside the timed region)
         try:
             gather(0, force=True)
             torch.cuda.synchronize(dev)
             mine = slice(rank * n_q, (rank + 1) * n_q)
             gather_ok = bool(torch.equal(g_ids[mine], d_ids[0]) and torch.equal(g_cnt[mine], d_cnt[0]))
+            env.barrier()
+            t0 = time.perf_counter()
+            for i in range(5):
+                gather(i % n_b, force=True)
+            torch.cuda.synchronize(dev)
+            tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gather_ms = float(tg.item())
         except Exception as exc:        # the timed region has no collective: report, do not lose the measurement
             log("result gather over RCCL failed: %r" % (exc,))
             gather_ok = False
@@ -274,6 +288,41 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         host = reps * n_q / (time.perf_counter() - t0)
         if not (np.array_equal(h_cnt, cnt[0]) and np.array_equal(h_ids, ids[0])):
             raise SystemExit("sg_suggest_batch (host buffers) and sg_suggest_batch_device disagree")
+
+    # ---- the same through sg_suggest_submit / sg_ticket_wait: pinned buffers, two tickets in flight from ONE host thread, so
+    #      the copies of one batch run beside the kernel of another (what the Go shim's dispatcher does) ----
+    piped = None
+    if rank == 0 and world == 1 and host_rate:
+        from suggest_amd.index import pinned_array
+        slots = []
+        for b in range(min(n_b, 4)):
+            qb, qo = batches[b]
+            pb = pinned_array((max(qb.size, 1),), np.uint8)[:qb.size]; pb[:] = qb
+            po = pinned_array((n_q + 1,), np.uint64); po[:] = qo
+            slots.append((pb, po, pinned_array((n_q, k), np.uint32), pinned_array((n_q, k), np.float64), pinned_array((n_q,), np.uint32)))
+
+        def submit(i):
+            pb, po, p_ids, p_sc, p_cnt = slots[i % len(slots)]
+            return index.suggest_submit(pb, po, w["metric"], w["similarity"], k, p_ids, p_sc, p_cnt)
+
+        in_flight = 2 if len(slots) >= 2 else 1
+        reps = max(8, min(steps, 20))
+        for i in range(len(slots)):                                  # warm-up: every slot once (allocates the engine's device blocks)
+            submit(i).wait()
+        t0 = time.perf_counter()
+        pending = []
+        for i in range(reps):
+            pending.append(submit(i))
+            if len(pending) > in_flight - 1 and i + 1 < reps:
+                pending.pop(0).wait()
+        for t in pending:
+            t.wait()
+        piped = reps * n_q / (time.perf_counter() - t0)
+        for b in range(len(slots)):
+            if not (np.array_equal(slots[b][4], cnt[b]) and np.array_equal(slots[b][2], ids[b]) and
+                    np.array_equal(slots[b][3].view(np.uint64), sc[b].view(np.uint64))):
+                raise SystemExit("sg_suggest_submit / sg_ticket_wait rows differ from sg_suggest_batch_device's (batch %d)" % b)
+        log("[%s] host buffers: synchronous %.2f M q/s, pipelined (%d tickets in flight, pinned) %.2f M q/s" % (w["name"], host / 1e6, in_flight, piped / 1e6))
 
     # ---- one process, a replica per GPU, sg_suggest_batch_multi (rank 0, after the timed region; the other ranks wait) ----
     replicas = None
@@ -344,7 +393,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
             if rec:
-                traffic, traffic_src = rec["bytes_per_launch"], "file: " + rec["source"]
+                traffic, traffic_src = rec["bytes_per_launch"], "file" + (" (the N=1 PMC figure of this workload, per GPU; no PMC pass at N>1)" if world > 1 else "") + ": " + rec["source"]
         except (OSError, ValueError):
             pass
     if traffic is None:
@@ -386,6 +435,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "parallelism": "query-sharded x%d, index replica per GPU, one process per GPU%s"
                                   % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
                    "rccl_gather_check": gather_ok,
+                   "gather_ms": gather_ms,       # the optional all_gather of one step's result rows (3 collectives, k*(u32,f64)+u32 per query), max over ranks, untimed region
+                   "per_rank": per_rank,
                    "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
                              "build": args.build},
                    "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt]))},
@@ -395,6 +446,10 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     if host:
         rec["host_buffers"] = {"value": host, "unit": "queries/s",
                                "note": "sg_suggest_batch: pageable host buffers in and out over PCIe, synchronous (never `value`)"}
+    if piped:
+        rec["host_buffers_pipelined"] = {"value": piped, "unit": "queries/s", "frac_of_device_resident": piped / (total_q / elapsed),
+                                         "note": "sg_suggest_submit / sg_ticket_wait from ONE host thread: pinned host buffers (sg_host_alloc), two tickets in "
+                                                 "flight, PCIe-inclusive (never `value`); rows equal the device-resident run's"}
     if replicas:
         rec["replicas_mode"] = replicas
     if parity:
@@ -466,7 +521,7 @@ def main():
     subs = []
     if args.sub_configs == "auto":
         if env.world == 1 and args.config == "headline" and not args.explicit_workload and args.dict_variant == "uniform":
-            subs = ["cfg3", "cfg4", "cfg2"]
+            subs = ["cfg3", "cfg4", "skewed", "cfg2", "cfg5"]
     elif args.sub_configs != "none":
         subs = [s for s in args.sub_configs.split(",") if s]
         if env.world > 1:
@@ -476,8 +531,34 @@ def main():
     sub_recs = {}
     for name in subs:       # cfg3 and cfg4 first: they share the headline's dictionary
         t0 = time.time()
-        sw = workload_of(args, name)
-        steps = max(5, min(args.steps, 10)) if name != "cfg4" else max(3, min(args.steps, 5))
+        if name == "cfg5":      # the spellchecker caller (bench_spell.py): its own model, its own record
+            import argparse
+            import bench_spell
+            _DICT_CACHE.clear()
+            sa = argparse.Namespace(**vars(args))
+            sa.dict_size = sa.queries = sa.topk = sa.similarity = None
+            sa.steps, sa.warmup, sa.cpu_sample = max(5, min(args.steps, 10)), 2, 4096
+            try:
+                r5 = bench_spell.run(sa, env=env)
+            except (Exception, SystemExit) as exc:      # a failed sub-record must not lose the main line
+                env.log("[cfg5] sub-record failed: %r" % (exc,))
+                r5 = None
+            if r5:
+                sub_recs[name] = {"workload": r5["config"]["workload"], "metric": r5["metric"], "value": r5["value"], "unit": r5["unit"], "steps": r5["steps"],
+                                  "ms_per_step": r5["ms_per_step"], "step_gpu_ms_avg": r5["roofline"]["step_gpu_ms_avg"],
+                                  "frac": r5["roofline"]["frac"], "achieved_gbps": r5["roofline"]["achieved"], "traffic": r5["roofline"]["traffic"],
+                                  "traffic_source": r5["roofline"]["traffic_source"], "kernels": r5["roofline"]["kernels"],
+                                  "bit_exact": (r5.get("parity_vs_oracle") or {}).get("bit_exact"),
+                                  "checked_queries": (r5.get("parity_vs_oracle") or {}).get("checked_queries"),
+                                  "cpu_baseline": r5["cpu_baseline"], "host_buffers": r5.get("host_buffers"),
+                                  "predictions_per_query": r5["config"]["predictions_per_query"]}
+                env.log("[cfg5] sub-record done in %.0fs" % (time.time() - t0))
+            continue
+        if name == "skewed":    # SURVEY.md 8d's skewed variant of the headline (Zipf symbols: long lists at q = 3)
+            sw = dict(CONFIGS["headline"], name="skewed", variant="skewed")
+        else:
+            sw = workload_of(args, name)
+        steps = max(5, min(args.steps, 10)) if name not in ("cfg4", "skewed") else max(3, min(args.steps, 5))
         r = measure(env, args, sw, steps, 2, cpu_baseline=False if args.no_cpu_baseline else 4.0, host_rate=False,
                     traffic_mode=args.traffic)
         if r:
@@ -561,9 +642,9 @@ def _live_traffic(args, w, log):
     if not rocprof:
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
-    steps, warm = (4, 2) if w["name"] != "cfg4" else (2, 1)
+    steps, warm = (4, 2) if w["name"] not in ("cfg4", "skewed") else (2, 1)
     cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
-           os.path.abspath(__file__), "--config", w["name"], "--dict-size", str(w["dict_size"]), "--queries", str(w["queries"]),
+           os.path.abspath(__file__), "--config", w["name"] if w["name"] in CONFIGS else "headline", "--dict-size", str(w["dict_size"]), "--queries", str(w["queries"]),
            "--ngram", str(w["ngram"]), "--metric", w["metric"], "--similarity", repr(w["similarity"]), "--topk", str(w["topk"]),
            "--batches", str(args.batches), "--dict-variant", w["variant"], "--build", args.build,
            "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none", "--sub-configs", "none"]

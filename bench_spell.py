@@ -18,6 +18,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def main(args):
+    out = run(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def run(args, env=None):
+    """-> the record (rank 0) or None.  `env`: bench.py's Env when called for a sub-record of the default run (N = 1: no
+    process group is made or destroyed here)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -37,7 +45,8 @@ def main(args):
     backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    own_group = world > 1 and env is None
+    if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")      # control plane only (barrier, max over the ranks' clocks): no data-path collective
 
@@ -144,6 +153,7 @@ def main(args):
         parity = {"checked_queries": int(n_s), "bit_exact": same}
         log("cpu %.0f predictions/s on %d threads, %.0f on one; GPU == oracle on the sample: %s" % (cpu["value"], cores, cpu["one_thread"]["value"], same))
 
+    out = None
     if rank == 0:
         # algorithmic bytes of the two searches (SURVEY.md 8d accounting): the autocomplete over all last words, the fuzzy
         # search over the queries that needed it (their count is not known on the host: upper bound = all, lower = none)
@@ -191,9 +201,10 @@ def main(args):
                                    "note": "sg_spell_predict_batch: pageable host buffers in and out over PCIe, synchronous (never `value`)"}
         if parity:
             out["parity_vs_oracle"] = parity
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    del sc, lm
+    if own_group:
         dist.destroy_process_group()
+    return out
 
 
 def _live_kernels(args, tokens, n_q, top_k, sim, n_b, log):

@@ -146,6 +146,26 @@ int sg_autocomplete_one_from(sg_index* index, const uint8_t* q_utf8, uint32_t le
 int sg_autocomplete_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t first_doc,
                                uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
 
+/* ---- asynchronous host-buffer calls -----------------------------------------------------------------
+ * Service.Suggest (pkg/suggest/service.go:105-139) is called with host strings and returns host rows; a Go host behind
+ * this ABI therefore lives on host buffers.  The synchronous calls above copy in, run and copy out one after the other;
+ * these let the copies of one batch run beside the kernel of another: submit returns once everything is enqueued (copy
+ * in -> search launch -> copy out, on three streams of the primary replica tied by events; all search launches of the
+ * replica stay serialised on one stream), sg_ticket_wait blocks until the rows are in the caller's buffers and frees the
+ * ticket.  Up to 8 tickets may be in flight per replica; two are enough to hide PCIe behind the kernel.  Buffers from
+ * sg_host_alloc (pinned) are read / written by the DMA engine directly; other buffers are staged through pinned memory
+ * (a memcpy at submit, one at wait).  The caller's buffers must stay valid and untouched until the wait returns.  Submit
+ * and wait may be called from different threads. */
+typedef struct sg_ticket sg_ticket;
+int sg_host_alloc(uint64_t bytes, void** out);
+void sg_host_free(void* p);
+int sg_suggest_submit(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
+                      double similarity, uint32_t k, uint32_t* out_ids, double* out_scores, uint32_t* out_counts,
+                      sg_ticket** out_ticket);
+int sg_autocomplete_submit(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t first_doc,
+                           uint32_t limit, uint32_t* out_ids, uint32_t* out_counts, sg_ticket** out_ticket);
+int sg_ticket_wait(sg_ticket* ticket);
+
 /* Reference counting: the Go shim retains while a query is in flight and releases from a
  * finalizer, mirroring the reference's mmap release (pkg/index/index_reader.go:49-51). */
 void sg_index_retain(sg_index* index);

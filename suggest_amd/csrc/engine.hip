@@ -798,7 +798,7 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_SUB], const u
 #ifdef SG_PHASE_TIMING   // tools/phase_timing.py: where do a wavefront's cycles go (s_memtime brackets)
 #define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_last = clock64();
 #define PH(n) { const long long ph_now = clock64(); ph_acc[n] += ph_now - ph_last; ph_last = ph_now; }
-#define PH_FLUSH if (lane < 8 && a.prof) { atomicAdd(a.prof + (qi & 4095u) * 8 + lane, (unsigned long long)ph_acc[lane]); \
+#define PH_FLUSH if (lane < 8 && a.prof && !((a.dbg_skip & 65536u) && !kLM) && !((a.dbg_skip & 131072u) && kLM)) { atomicAdd(a.prof + (qi & 4095u) * 8 + lane, (unsigned long long)ph_acc[lane]); \
                                              atomicAdd(a.prof + 4096 * 8 + (qi & 4095u) * 8 + lane, (unsigned long long)dbg_n[lane]); }
 #define DBG_SKIP(bit) (a.dbg_skip & (bit))
 #define DBG_COUNT(slot, v) dbg_n[slot] += (v);
@@ -1333,15 +1333,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         uint64_t key;
         if (kLM) {                                              // lmCollector: ScoreNext is monotone in the continuation count
           uint32_t myc = 0;
-          uint64_t pm = ballot(pass);
-          while (pm) {
-            const int l = __builtin_ctzll(pm);
-            pm &= pm - 1;
-            const uint32_t d = readlane(my_orig, l);
-            uint32_t c;
-            if (lm_small) { const uint64_t mm = ballot(lm_w == d); c = mm ? readlane(lm_c, __builtin_ctzll(mm)) : 0u; }
-            else c = d_lm_count(a.lm_values, lm_from, lm_to, d, lane);
-            if (lane == l) myc = c;
+          if (lm_small) {
+            uint64_t pm = ballot(pass);
+            while (pm) {
+              const int l = __builtin_ctzll(pm);
+              pm &= pm - 1;
+              const uint32_t d = readlane(my_orig, l);
+              const uint64_t mm = ballot(lm_w == d);
+              const uint32_t c = mm ? readlane(lm_c, __builtin_ctzll(mm)) : 0u;
+              if (lane == l) myc = c;
+            }
+          } else if (pass) {
+            // A context with more than 64 continuations (the frequent words: thousands): every lane searches ITS candidate's
+            // word in the sorted list — log2(n) dependent loads for the 64 candidates of the flush together.  One wave-wide
+            // 64-ary search per candidate (d_lm_count), a memory round trip or two each inside a serial loop, made a
+            // two-letter prefix behind a frequent context (1 400 matches) a 3 ms wavefront: the launch's tail, with the
+            // machine half empty behind it (SQ_WAVE_CYCLES: 46 % of the wave slots occupied, profiles/r04a_pmc_cfg5.txt).
+            uint32_t lo = lm_from, hi = lm_to;
+            while (lo < hi) {
+              const uint32_t mid = lo + ((hi - lo) >> 1);
+              if ((uint32_t)(a.lm_values[mid] >> 32) < my_orig) lo = mid + 1u; else hi = mid;
+            }
+            if (lo < lm_to) { const uint64_t v = a.lm_values[lo]; if ((uint32_t)(v >> 32) == my_orig) myc = (uint32_t)v; }
           }
           key = (uint64_t)myc;
         } else if (a.autocomplete) {                            // score = -docID, collector.go:104-106
@@ -1929,7 +1942,8 @@ __device__ __forceinline__ uint32_t long_gram_hash(const uint32_t* runes, uint32
 
 // The tokeniser of NewSuggestTokenizer / NewAutocompleteTokenizer (pkg/suggest/tokenizer.go:9-34) for texts of any length
 // up to SG_LONG_MAX_TERMS bytes, with its tables in an HBM slot: wrap -> lower -> trim -> q-grams (first-occurrence
-// dedup) -> normalise.  Returns the number of n-grams; their packed keys are in the slot's `keys`.  Shared by the
+// dedup) -> normalise.  Returns the number of n-grams (0xFFFFFFFF: more than SG_LONG_MAX_TERMS of them before the dedup —
+// the tables would overflow); their packed keys are in the slot's `keys`.  Shared by the
 // long-query kernel and the device index builder's long documents.
 __device__ uint32_t long_tokenize(const DeviceIndex& ix, bool autocomplete, const uint8_t* q, uint32_t qlen, uint8_t* slot, int lane) {
   uint32_t* runes = (uint32_t*)(slot + LongSlot::o_runes);
@@ -1973,6 +1987,9 @@ __device__ uint32_t long_tokenize(const DeviceIndex& ix, bool autocomplete, cons
     // appendUnique (ngram_tokenizer.go:46-54): a gram stays where it FIRST occurs.  htab: the smallest position of every
     // distinct gram (open addressing on the runes of the window; equal windows meet in one slot and keep the minimum).
     const uint32_t G = t1 - t0 - q_n + 1;
+    // (the slot's tables are sized in n-grams, not bytes: wrap strings of q runes or more — q = 2 with '$', '$' — make more
+    //  n-grams than the text has bytes; beyond the tables the text is rejected like one of too many bytes)
+    if (G > SG_LONG_MAX_TERMS) return 0xFFFFFFFFu;
     uint32_t H = 64;
     while (H < 2u * G) H <<= 1;
     for (uint32_t i = lane; i < H; i += 64) htab[i] = 0xFFFFFFFFu;
@@ -2020,6 +2037,7 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
   if (qlen64 > SG_LONG_MAX_TERMS) return;                       // stays SG_COUNT_TOO_LONG
   const uint32_t qlen = (uint32_t)qlen64, k = a.k;
   const uint32_t A = long_tokenize(ix, a.autocomplete != 0, q, qlen, slot, lane);
+  if (A == 0xFFFFFFFFu) return;                                 // more n-grams than the slot's tables: stays SG_COUNT_TOO_LONG
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
   if (ix.slots) for (uint32_t i = lane; i < A; i += 64) term[i] = d_term_lookup(ix, keys[i]);
   __syncthreads();

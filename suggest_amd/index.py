@@ -48,6 +48,43 @@ def _c_desc(d):
     return desc
 
 
+class Ticket:
+    """A batch in flight (sg_ticket).  wait() must be called exactly once; the buffers of the submit are kept alive here."""
+
+    def __init__(self, handle, keep):
+        self._t, self._keep = handle, keep
+
+    def wait(self):
+        t, self._t = self._t, None
+        if t is None:
+            raise ValueError("ticket already waited for")
+        try:
+            _lib.check(_lib.lib().sg_ticket_wait(t))
+        finally:
+            self._keep = None
+
+    def __del__(self):
+        if getattr(self, "_t", None) is not None:     # never waited for: the engine still owns the slot and a reference
+            try:
+                _lib.lib().sg_ticket_wait(self._t)
+            except Exception:
+                pass
+
+
+def pinned_array(shape, dtype):
+    """numpy array over pinned host memory (sg_host_alloc): the buffers of sg_*_submit that need no staging copy.  The
+    memory is handed back (sg_host_free) when the last view of the array goes."""
+    import weakref
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    n = max(count * dtype.itemsize, 16)
+    p = C.c_void_p()
+    _lib.check(_lib.lib().sg_host_alloc(n, C.byref(p)))
+    buf = (C.c_uint8 * n).from_address(p.value)
+    weakref.finalize(buf, _lib.lib().sg_host_free, p.value)
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
 class NGramIndex:
     def __init__(self, docs=None, description=None, blob=None, offs=None, device=0, upload=True, _handle=None, build="host", min_segments=0):
         """build="host": sg_index_build (CPU tokenise + CSR); build="device": sg_index_build_device (same arrays, built on the
@@ -208,6 +245,29 @@ class NGramIndex:
             if c < page or out[-1] == 0xFFFFFFFF:
                 return out
             first = out[-1] + 1
+
+    # ---- search: host buffers, asynchronous (sg_suggest_submit / sg_ticket_wait) -----------------
+    def suggest_submit(self, blob, offs, metric, similarity, k, ids, scores, counts):
+        """Enqueues copy in -> search -> copy out for one batch and returns a ticket; `ticket.wait()` blocks until the rows
+        are in ids / scores / counts.  All six arrays must stay alive and untouched until then; arrays from `pinned_array`
+        are read / written by the DMA engine directly.  Two tickets in flight hide PCIe behind the kernel."""
+        n_q = len(offs) - 1
+        assert offs.dtype == np.uint64 and blob.dtype == np.uint8 and ids.dtype == np.uint32 and scores.dtype == np.float64 and counts.dtype == np.uint32
+        assert ids.size >= n_q * k and scores.size >= n_q * k and counts.size >= n_q
+        t = C.c_void_p()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_suggest_submit(h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code,
+                                                    float(similarity), int(k), ids.ctypes.data, scores.ctypes.data, counts.ctypes.data, C.byref(t)))
+        return Ticket(t, (blob, offs, ids, scores, counts))
+
+    def autocomplete_submit(self, blob, offs, limit, ids, counts, first_doc=0):
+        n_q = len(offs) - 1
+        assert offs.dtype == np.uint64 and blob.dtype == np.uint8 and ids.dtype == np.uint32 and counts.dtype == np.uint32
+        t = C.c_void_p()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_autocomplete_submit(h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, int(first_doc), int(limit),
+                                                         ids.ctypes.data, counts.ctypes.data, C.byref(t)))
+        return Ticket(t, (blob, offs, ids, counts))
 
     # ---- search: device-resident buffers (raw pointers; torch tensors' data_ptr()) ---------
     def suggest_batch_device(self, d_blob, d_offs, n_q, metric, similarity, k, d_ids, d_scores, d_counts, stream=0):

@@ -65,12 +65,12 @@ def big_q3():
 
 def test_headline_10m_jaccard_k10(big_q3):
     """the configuration BASELINE.json's metric is quoted on: 10 M strings, q=3, Jaccard >= 0.5, k=10, 65,536 queries"""
-    big_q3.check("jaccard", 0.5, 10, every=16)
+    big_q3.check("jaccard", 0.5, 10, every=1)       # every row: the oracle does 26 k q/s on that box
 
 
 def test_cfg3_10m_cosine_k20(big_q3):
     """BASELINE config 3: 10 M strings, q=3, Cosine >= 0.4, k=20 (window = every segment, T about 8)"""
-    ids, sc, cnt = big_q3.check("cosine", 0.4, 20, every=16)
+    ids, sc, cnt = big_q3.check("cosine", 0.4, 20, every=1)
     # the device-resident entry point gives the same rows as the host-buffer one (same launch, other plumbing)
     import torch
     dev = torch.device("cuda", 0)
@@ -91,7 +91,7 @@ def test_cfg4_10m_q2_dice_k10():
     """BASELINE config 4: 10 M strings, q=2 (13 MB of postings per query), Dice >= 0.5, k=10"""
     b = Big(10_000_000, 2)
     try:
-        b.check("dice", 0.5, 10, every=32)
+        b.check("dice", 0.5, 10, every=4)
     finally:
         b.gpu.close(); b.ora.close()
 
@@ -109,7 +109,7 @@ def test_cfg5_spellchecker_50m_token_model(tmp_path_factory):
     """BASELINE config 5 at its size: SpellChecker.Predict (pkg/spellchecker/spellchecker.go:40-92) over a 50 M-token
     synthetic 3-gram model in the reference's own .lm / .cdb formats (tools/make_synthetic_lm.py: ~1 M-word vocabulary, ids
     by count like `lm build-lm`), the vocabulary's fuzzy index + the LM arrays resident on the GPU.  A 65,536-query batch
-    ('w1 w2 prefix', one third with a typo in the last word) goes through sg_spell_predict_batch; 4,096 sampled queries are
+    ('w1 w2 prefix', one third with a typo in the last word) goes through sg_spell_predict_batch; 16,384 sampled queries are
     compared with the oracle's Predict row by row (ids and order), the rest is held to the path's invariants."""
     import os
     import sys
@@ -134,7 +134,7 @@ def test_cfg5_spellchecker_50m_token_model(tmp_path_factory):
     assert (ids[valid] < len(lm)).all()
     srt = np.sort(np.where(valid, ids.astype(np.int64), -np.arange(1, top_k + 2)[None, :]), axis=1)
     assert (srt[:, 1:] != srt[:, :-1]).all()                            # no word twice in a row of predictions
-    rows = np.arange(0, N_Q, 16)
+    rows = np.arange(0, N_Q, 4)
     sb, so = _subset(qb, qo, rows)
     olm = oracle.OracleLM(binary=os.path.join(d, "synth.lm"), dictionary=os.path.join(d, "synth.cdb"))
     oix = oracle.OracleIndex(info["word_list"], ngram_size=sc.description.ngram_size, wrap=sc.description.wrap, pad=sc.description.pad,

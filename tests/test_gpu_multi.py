@@ -310,3 +310,68 @@ def test_device_pairsort_matches_the_other_two_go_sort_restatements():
         out = np.zeros(n, dtype=np.uint32)
         _lib.check(L.sg_debug_pairsort(0, keys.ctypes.data, n, out.ctypes.data))
         assert out.tolist() == gosort.go_sort(keys.tolist()) == oracle.go_sort(keys), (trial, keys.tolist())
+
+
+def test_async_submit_wait_pinned_and_pageable(small):
+    """sg_suggest_submit / sg_ticket_wait: several tickets in flight (copy in, launch and copy out of different batches
+    overlap on three streams), pinned buffers (no staging) and pageable ones (staged), waited for in another order and
+    from another thread than they were submitted in; every row equals the synchronous call's"""
+    from suggest_amd.index import pinned_array
+    gpu, ora, qb, qo = small
+    k = 10
+    cuts = [0, 700, 701, 2500, 5000]                       # four batches of different sizes, the second a single query
+    ref = gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=k)
+    tickets, outs = [], []
+    for b in range(4):
+        lo, hi = cuts[b], cuts[b + 1]
+        n = hi - lo
+        blob = qb[int(qo[lo]):int(qo[hi])]
+        offs = (qo[lo:hi + 1] - qo[lo]).astype(np.uint64)
+        if b % 2 == 0:                                      # pinned: DMA straight from / to the caller's arrays
+            pb = pinned_array((max(blob.size, 1),), np.uint8)[:blob.size]; pb[:] = blob
+            po = pinned_array((n + 1,), np.uint64); po[:] = offs
+            ids, sc, cnt = pinned_array((n, k), np.uint32), pinned_array((n, k), np.float64), pinned_array((n,), np.uint32)
+            ids[:] = 0xDEAD; sc[:] = -1; cnt[:] = 77
+            blob, offs = pb, po
+        else:                                               # pageable, and offsets that do not start at zero (a slice of a larger batch)
+            blob, offs = qb, qo[lo:hi + 1].copy()
+            ids, sc, cnt = np.full((n, k), 0xDEAD, np.uint32), np.full((n, k), -1.0), np.full((n,), 77, np.uint32)
+        tickets.append(gpu.suggest_submit(blob, offs, "jaccard", 0.5, k, ids, sc, cnt))
+        outs.append((ids, sc, cnt))
+    errs = []
+
+    def waiter(order):
+        try:
+            for i in order:
+                tickets[i].wait()
+        except Exception as e:   # noqa
+            errs.append(e)
+    th = threading.Thread(target=waiter, args=([3, 1],))
+    th.start()
+    waiter([2, 0])
+    th.join()
+    assert not errs, errs
+    for b in range(4):
+        lo, hi = cuts[b], cuts[b + 1]
+        ids, sc, cnt = outs[b]
+        assert np.array_equal(cnt, ref[2][lo:hi])
+        assert np.array_equal(ids, ref[0][lo:hi])
+        assert np.array_equal(sc.view(np.uint64), ref[1][lo:hi].view(np.uint64))
+    with pytest.raises(ValueError):
+        tickets[0].wait()                                   # a ticket is waited for once
+    # autocomplete through the same machinery, with a first_doc; an empty batch; more tickets than slots
+    a_ref = gpu.autocomplete_batch(blob=qb[:int(qo[300])], offs=qo[:301], limit=5)
+    a_ids, a_cnt = np.zeros((300, 5), np.uint32), np.zeros(300, np.uint32)
+    gpu.autocomplete_submit(qb[:int(qo[300])], qo[:301].copy(), 5, a_ids, a_cnt).wait()
+    assert np.array_equal(a_cnt, a_ref[1]) and np.array_equal(a_ids, a_ref[0])
+    gpu.suggest_submit(np.zeros(0, np.uint8), np.zeros(1, np.uint64), "jaccard", 0.5, k, np.zeros((0, k), np.uint32), np.zeros((0, k)), np.zeros(0, np.uint32)).wait()
+    from suggest_amd._lib import SuggestHipError
+    many = []
+    with pytest.raises(SuggestHipError, match="tickets in flight"):
+        for _ in range(9):
+            many.append(gpu.suggest_submit(qb[:int(qo[10])], qo[:11].copy(), "jaccard", 0.5, k, np.zeros((10, k), np.uint32), np.zeros((10, k)), np.zeros(10, np.uint32)))
+    assert len(many) == 8
+    for t in many:
+        t.wait()
+    t = gpu.suggest_submit(qb[:int(qo[10])], qo[:11].copy(), "jaccard", 0.5, k, np.zeros((10, k), np.uint32), np.zeros((10, k)), np.zeros(10, np.uint32))
+    t.wait()                                                 # the slots are free again
