@@ -146,6 +146,32 @@ int sg_autocomplete_one_from(sg_index* index, const uint8_t* q_utf8, uint32_t le
 int sg_autocomplete_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t first_doc,
                                uint32_t limit, uint32_t* out_ids, uint32_t* out_counts);
 
+/* ---- the Suggester seam for ANY Metric and ANY collector (pkg/suggest/suggester.go:17-20) -------------------------
+ * metric.Metric is an interface (pkg/metric/metric.go:7-16: MinY, MaxY, Threshold, Distance); the five implementations
+ * above have device twins, any other one reaches the engine as tables its binding fills by calling the four methods:
+ *   min_y[a], max_y[a]                      a = 0 .. a_max          Metric.MinY / MaxY(alpha, a)
+ *   threshold[a * S + b]                    b = 0 .. S - 1          Metric.Threshold(alpha, a, b)
+ *   score[(a * S + b) * (a_max + 1) + o]    o = 0 .. a_max          1 - Metric.Distance(o, a, b)   (scorer.go:29-31)
+ * S = sg_stats.n_segments of `index`.  A query with more than a_max n-grams comes back SG_COUNT_TOO_LONG.  The tables are
+ * copied to the HBM of the index's primary replica and live until released (they retain the index). */
+typedef struct sg_metric_tables sg_metric_tables;
+int sg_metric_tables_create(sg_index* index, uint32_t a_max, const int32_t* min_y, const int32_t* max_y,
+                            const int32_t* threshold, const double* score, sg_metric_tables** out);
+void sg_metric_tables_release(sg_metric_tables* tables);
+/* sg_suggest_batch under a tabulated metric: same rows, same order. */
+int sg_suggest_batch_tables(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                            const sg_metric_tables* tables, uint32_t k, uint32_t* out_ids, double* out_scores,
+                            uint32_t* out_counts);
+/* nGramSuggester.Suggest hands EVERY document whose overlap reaches the segment's threshold to the caller's collector
+ * (suggester.go:78-99; the fuzzy top-k manager is only the usual one).  For a binding that must serve another collector:
+ * row i = the `limit` smallest docIDs >= first_doc among query i's candidates over all admissible segments, ascending,
+ * with their scores and (out_aux, may be NULL) segment << 16 | overlap — enough to rebuild
+ * merger.MergeCandidate{Position, Overlap} and the segment's scorer.  Page with first_doc = last docID of a full page + 1.
+ * `tables` non-NULL replaces (metric, similarity). */
+int sg_suggest_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
+                          double similarity, const sg_metric_tables* tables, uint32_t first_doc, uint32_t limit,
+                          uint32_t* out_ids, double* out_scores, uint32_t* out_aux, uint32_t* out_counts);
+
 /* ---- asynchronous host-buffer calls -----------------------------------------------------------------
  * Service.Suggest (pkg/suggest/service.go:105-139) is called with host strings and returns host rows; a Go host behind
  * this ABI therefore lives on host buffers.  The synchronous calls above copy in, run and copy out one after the other;

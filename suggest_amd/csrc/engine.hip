@@ -117,6 +117,15 @@ struct DeviceIndex {
   uint8_t pad_sym[8];
 };
 
+#define SG_TABLE 5   // BatchArgs::metric: MinY / MaxY / Threshold / 1 - Distance come from host-built tables
+struct MetricTab {   // [a] = query cardinality 0..a_max, [b] = segment 0..S-1, [o] = overlap 0..a_max
+  const int32_t* min_y;      // [a_max + 1]
+  const int32_t* max_y;      // [a_max + 1]
+  const int32_t* thr;        // [(a_max + 1) * S]            Threshold(alpha, a, b)
+  const double* score;       // [(a_max + 1) * S * (a_max + 1)]   1 - Distance(o, a, b), as the scorer computes it (scorer.go:29-31)
+  uint32_t a_max, S;
+};
+
 struct BatchArgs {
   DeviceIndex ix;
   const uint8_t* q_blob;
@@ -129,7 +138,7 @@ struct BatchArgs {
   uint32_t* scratch_id;
   double alpha;
   uint32_t n_q, k;
-  int metric, autocomplete;
+  int metric, autocomplete;   // autocomplete: 0 fuzzy top-k by score, 1 prefix search (first-k docIDs), 2 fuzzy, first-k docIDs >= ac_first (any collector)
   uint32_t log2_cnt;    // LDS counter words per wave = 1 << log2_cnt
   int t_floor;          // lowest flag threshold list skipping may leave
   uint32_t filter_level;  // row of kBucketsPer16Postings: how rarely a bucket may reach T by chance
@@ -157,7 +166,14 @@ struct BatchArgs {
   uint64_t long_slot_bytes;
   uint32_t* long_list;    // [1 + n_q] the wavefront kernel's list of such queries: [0] = how many (zeroed per launch), then their indices
   uint32_t long_max_seg;  // documents of the largest cardinality segment (the slot's counter array)
-  uint32_t ac_first;      // autocomplete: only documents with docID >= this (a caller that wants every match pages through them)
+  uint32_t ac_first;      // autocomplete / by_doc: only documents with docID >= this (a caller that wants every match pages through them)
+  // ---- an opaque metric.Metric implementation (pkg/metric/metric.go:7-16), tabulated by the host: metric == SG_TABLE ----
+  MetricTab mt;
+  // ---- fuzzy search for ANY collector (suggester.go:78-99 hands every candidate with overlap >= T to the caller's collector):
+  //      the `k` smallest docIDs >= ac_first among them instead of the k best scores; top-k key = ~docID << 32 | segment << 16 |
+  //      overlap (the score is computed from it on the way out), out_aux receives the key's low word ----
+  //      = autocomplete == 2 (one mode word: a second flag beside it made the compiler keep all of BatchArgs on the stack)
+  uint32_t* out_aux;      // [n_q][k] segment << 16 | overlap of every row (autocomplete == 2 only; may be null)
   // ---- the tokeniser as a launch of its own (sg_terms_kernel, big batches): the search kernel then starts from the term ids ----
   int32_t* pre_A;         // [n_q] d_tokenize's result per query (null: the search kernel tokenises itself)
   uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
@@ -176,8 +192,9 @@ __device__ __forceinline__ uint32_t readlane(uint32_t v, int l) { return (uint32
 
 // pkg/metric — IEEE binary64, Go's evaluation order; built with -ffp-contract=off
 __device__ double d_floor_div_clamp(double x, double hi) { double f = floor(x); return f > hi ? hi : f; }
-__device__ int d_min_y(int m, double alpha, int size) {
+__device__ __forceinline__ int d_min_y(int m, double alpha, int size, const MetricTab& mt) {
   switch (m) {
+    case SG_TABLE: return mt.min_y[size];
     case SG_JACCARD: return (int)ceil(alpha * (double)size);
     case SG_COSINE: return (int)ceil(alpha * alpha * (double)size);
     case SG_DICE: return (int)ceil(alpha / (2 - alpha) * (double)size);
@@ -185,9 +202,10 @@ __device__ int d_min_y(int m, double alpha, int size) {
     default: return 1;
   }
 }
-__device__ int d_max_y(int m, double alpha, int size, int cap) {  // result clamped to cap (>= any usable bMax)
+__device__ __forceinline__ int d_max_y(int m, double alpha, int size, int cap, const MetricTab& mt) {  // result clamped to cap (>= any usable bMax)
   double v;
   switch (m) {
+    case SG_TABLE: { const int t = mt.max_y[size]; return t > cap ? cap : t; }
     case SG_JACCARD: v = floor((double)size / alpha); break;
     case SG_COSINE: v = floor((double)size / (alpha * alpha)); break;
     case SG_DICE: v = floor((2 - alpha) / alpha * (double)size); break;
@@ -196,8 +214,9 @@ __device__ int d_max_y(int m, double alpha, int size, int cap) {  // result clam
   }
   return v > (double)cap ? cap : (int)v;
 }
-__device__ int d_threshold(int m, double alpha, int a, int b) {
+__device__ __forceinline__ int d_threshold(int m, double alpha, int a, int b, const MetricTab& mt) {
   switch (m) {
+    case SG_TABLE: return (uint32_t)b < mt.S ? mt.thr[(uint32_t)a * mt.S + (uint32_t)b] : 0;
     case SG_JACCARD: return (int)ceil(alpha * (double)(a + b) / (1 + alpha));
     case SG_COSINE: return (int)ceil(alpha * sqrt((double)((long long)a * (long long)b)));   // (Go's int is 64 bits wide)
     case SG_DICE: return (int)ceil(0.5 * alpha * (double)(a + b));
@@ -205,9 +224,10 @@ __device__ int d_threshold(int m, double alpha, int a, int b) {
     default: return (int)ceil(alpha * fmin((double)a, (double)b));
   }
 }
-__device__ double d_score(int m, int inter, int a, int b) {  // 1 - Distance(...), two roundings
+__device__ __forceinline__ double d_score(int m, int inter, int a, int b, const MetricTab& mt) {  // 1 - Distance(...), two roundings
   double dist;
   switch (m) {
+    case SG_TABLE: return mt.score[((uint64_t)((uint32_t)a * mt.S + (uint32_t)b)) * (mt.a_max + 1u) + (uint32_t)min(inter, (int)mt.a_max)];
     case SG_JACCARD: dist = 1 - (double)inter / (double)(a + b - inter); break;
     case SG_COSINE: dist = 1 - (double)inter / sqrt((double)((long long)a * (long long)b)); break;
     case SG_DICE: dist = 1 - (double)(2 * inter) / (double)(a + b); break;
@@ -222,7 +242,7 @@ __device__ __forceinline__ uint64_t score_bits(double x);
 // only enter it with a score >= the k-th best, i.e. with an overlap >= the smallest o whose score reaches it.  Scores are
 // compared as the bit patterns the results carry, upwards from the metric's own threshold — no inverse formula, no
 // rounding argument; ties stay in (the docID decides them at the insertion).  Returns omax + 1 when no overlap will do.
-__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s);
+__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s, const MetricTab mt);
 
 __device__ __forceinline__ uint64_t score_bits(double x) {
   uint64_t b = (uint64_t)__double_as_longlong(x);
@@ -232,9 +252,14 @@ __device__ __forceinline__ double bits_score(uint64_t k) {
   uint64_t b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
   return __longlong_as_double((long long)b);
 }
-__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s) {
-  while (t <= omax && score_bits(d_score(m, t, a, b)) < worst_s) t++;
+__device__ __noinline__ int d_tighten(int m, int t, int omax, int a, int b, uint64_t worst_s, const MetricTab mt) {   // (by value: a reference into the kernel argument would put all of BatchArgs on the stack)
+  while (t <= omax && score_bits(d_score(m, t, a, b, mt)) < worst_s) t++;
   return t;
+}
+// by_doc mode: the top-k keeps the SMALLEST docIDs; segment and overlap ride in the low word (the score is computed from
+// them when the rows are written out: the same d_score call as the score-ordered path, bit for bit)
+__device__ __forceinline__ uint64_t by_doc_key(uint32_t d, int overlap, int b) {
+  return ((uint64_t)(~d) << 32) | (uint64_t)(((uint32_t)b & 0xFFFFu) << 16) | (uint64_t)((uint32_t)overlap & 0xFFFFu);
 }
 __device__ __forceinline__ bool better(uint64_t s1, uint32_t i1, uint64_t s2, uint32_t i2) {
   return s1 > s2 || (s1 == s2 && i1 < i2);  // Candidate.Less inverted, collector.go:20-26
@@ -362,7 +387,7 @@ __device__ uint32_t d_lm_count(const uint64_t* values, uint32_t from, uint32_t t
 __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
                           uint32_t* term, int lane) {
   const DeviceIndex& ix = a.ix;
-  const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete ? 0u : ix.n_wrap1;
+  const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete == 1 ? 0u : ix.n_wrap1;
   // ASCII?
   bool na = false;
   for (uint32_t i = lane; i < qlen; i += 64) {            // one pass over the bytes: ASCII test and, optimistically, the runes
@@ -949,6 +974,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     break;
   }
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; break; }
+  if (a.metric == SG_TABLE && (uint32_t)A > a.mt.a_max) { if (lane == 0) a.out_counts[qi] = SG_COUNT_TOO_LONG; break; }   // the tables end before this cardinality
   auto build_qhash = [&]() {
     for (uint32_t i = lane; i < L::qh; i += 64) qh_key[i] = kNoTerm;
     __syncthreads();
@@ -964,10 +990,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
   const int S = (int)ix.S;
   int b_min, b_max;
-  if (a.autocomplete) { b_min = A; b_max = S - 1; }     // autocomplete.go:47
+  if (a.autocomplete == 1) { b_min = A; b_max = S - 1; }     // autocomplete.go:47
   else {
-    b_min = d_min_y(a.metric, a.alpha, A);
-    b_max = d_max_y(a.metric, a.alpha, A, S);             // suggester.go:54-59
+    b_min = d_min_y(a.metric, a.alpha, A, a.mt);
+    b_max = d_max_y(a.metric, a.alpha, A, S, a.mt);       // suggester.go:54-59
     if (b_max >= S) b_max = S - 1;
     const int span = b_max - b_min + 1;                    // suggester.go:62 make(chan int, span)
     if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; break; }
@@ -1065,13 +1091,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const uint32_t ne = seg_ne;
       seg_tot = seg_vol;
       const int B = tb + lane;
-      if (a.autocomplete) { seg_T = A; seg_valid = true; }
+      if (a.autocomplete == 1) { seg_T = A; seg_valid = true; }
       else {
-        seg_T = d_threshold(a.metric, a.alpha, A, B);
+        seg_T = d_threshold(a.metric, a.alpha, A, B, a.mt);
         seg_valid = !(seg_T == 0 || seg_T > B || seg_T > A);       // suggester.go:76
-        if (kTight && seg_valid && tk.n == k) {                      // the top-k is full
+        if (kTight && seg_valid && tk.n == k) {                      // the top-k is full (the docID-ordered modes never get here: seg_T is set above / the host takes the plain instantiation)
           // (a query that repeats a term counts it per occurrence: overlaps reach A even where B is smaller)
-          seg_T = d_tighten(a.metric, seg_T, A, A, B, tk.worst_s);
+          seg_T = d_tighten(a.metric, seg_T, A, A, B, tk.worst_s, a.mt);
           seg_valid = seg_T <= A;
         }
       }
@@ -1144,8 +1170,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         else c = d_lm_count(a.lm_values, lm_from, lm_to, d, lane);
         topk_insert(tk, (uint64_t)c, d, lane);
       }
-      else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }   // score = -docID, collector.go:104-106
-      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w)), d, lane);
+      else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, a.autocomplete == 2 ? by_doc_key(d, overlap, tb + w) : ~(uint64_t)d, d, lane); }   // score = -docID, collector.go:104-106
+      else topk_insert(tk, score_bits(d_score(a.metric, overlap, A, tb + w, a.mt)), d, lane);
     };
     // which query-term occurrences hold doc d in segment w, by binary search in their lists: only documents that repeat a
     // term come here (the secondary entries of SURVEY.md §A.3 need the per-list view)
@@ -1187,7 +1213,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           __syncthreads();
           exact_masks(x, w, fm);
           // (which secondary entries CPMerge produces depends on the threshold it ran with: the metric's own, not the tightened one)
-          const int T0 = a.autocomplete ? A : d_threshold(a.metric, a.alpha, A, tb + w);
+          const int T0 = a.autocomplete == 1 ? A : d_threshold(a.metric, a.alpha, A, tb + w, a.mt);
           dup_secondary_overlaps(ix, term, rows, dup_scratch, A, stride, w, (uint32_t)(tb + w), T0, d, fm[0], fm[1], lane,
                                  [&](int extra_overlap) { offer(d, extra_overlap, w); });
           __syncthreads();
@@ -1358,9 +1384,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           }
           key = (uint64_t)myc;
         } else if (a.autocomplete) {                            // score = -docID, collector.go:104-106
-          key = ~(uint64_t)my_orig;
+          key = a.autocomplete == 2 ? by_doc_key(my_orig, ov, tb + wseg) : ~(uint64_t)my_orig;
           pass = pass && (dupd || my_orig >= a.ac_first);
-        } else key = score_bits(d_score(a.metric, ov, A, tb + wseg));
+        } else key = score_bits(d_score(a.metric, ov, A, tb + wseg, a.mt));
         uint64_t m = ballot(pass && !dupd);
         while (m) {
           if (tk.n == k) { m &= ballot(better(key, my_orig, tk.worst_s, tk.worst_id)); if (!m) break; }
@@ -1856,7 +1882,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       rank += (better(sj, dj, s, d) || (sj == s && dj == d && j < i)) ? 1u : 0u;
     }
     out_ids[rank] = d;
-    if (out_scores) out_scores[rank] = bits_score(s);
+    if (a.autocomplete == 2) {
+      if (out_scores) out_scores[rank] = d_score(a.metric, (int)(s & 0xFFFFu), A, (int)((s >> 16) & 0xFFFFu), a.mt);
+      if (a.out_aux) a.out_aux[(uint64_t)qi * k + rank] = (uint32_t)s;
+    } else if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
   if (!kLM && !a.autocomplete && a.fill_stat && lane == 0 && (qi & a.fill_mask) == 0u) {
@@ -2036,18 +2065,19 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
   const uint64_t qlen64 = qe - qb;
   if (qlen64 > SG_LONG_MAX_TERMS) return;                       // stays SG_COUNT_TOO_LONG
   const uint32_t qlen = (uint32_t)qlen64, k = a.k;
-  const uint32_t A = long_tokenize(ix, a.autocomplete != 0, q, qlen, slot, lane);
+  const uint32_t A = long_tokenize(ix, a.autocomplete == 1, q, qlen, slot, lane);
   if (A == 0xFFFFFFFFu) return;                                 // more n-grams than the slot's tables: stays SG_COUNT_TOO_LONG
   if (A == 0) { if (lane == 0) a.out_counts[qi] = 0; return; }
+  if (a.metric == SG_TABLE && A > a.mt.a_max) return;            // the tables end before this cardinality: stays SG_COUNT_TOO_LONG
   if (ix.slots) for (uint32_t i = lane; i < A; i += 64) term[i] = d_term_lookup(ix, keys[i]);
   __syncthreads();
   // ---- window (suggester.go:53-62) ----
   const int S = (int)ix.S;
   int b_min, b_max;
-  if (a.autocomplete) { b_min = (int)A; b_max = S - 1; }
+  if (a.autocomplete == 1) { b_min = (int)A; b_max = S - 1; }
   else {
-    b_min = d_min_y(a.metric, a.alpha, (int)A);
-    b_max = d_max_y(a.metric, a.alpha, (int)A, S);
+    b_min = d_min_y(a.metric, a.alpha, (int)A, a.mt);
+    b_max = d_max_y(a.metric, a.alpha, (int)A, S, a.mt);
     if (b_max >= S) b_max = S - 1;
     const int span = b_max - b_min + 1;
     if (span < 0) { if (lane == 0) a.out_counts[qi] = SG_COUNT_REF_PANIC; return; }
@@ -2062,8 +2092,8 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
   const uint32_t S1 = (uint32_t)S + 1u;
   for (int B = b_min; B <= b_max; B++) {
     int T = (int)A;
-    if (!a.autocomplete) {
-      T = d_threshold(a.metric, a.alpha, (int)A, B);
+    if (a.autocomplete != 1) {
+      T = d_threshold(a.metric, a.alpha, (int)A, B, a.mt);
       if (T == 0 || T > B || T > (int)A) continue;               // suggester.go:76
     }
     const uint32_t x0 = ix.seg_base[B], n_seg = ix.seg_base[B + 1] - x0;
@@ -2097,7 +2127,7 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
       // lane <-> candidate: docID and top-k key side by side; once the top-k is full one compare per lane leaves the few that
       // can still enter it (and with them their secondary entries: same docID, at most the same overlap)
       const uint32_t dj = ((m >> lane) & 1ull) ? ix.orig_of[x0 + j] : 0u;
-      const uint64_t keyj = a.autocomplete ? ~(uint64_t)dj : score_bits(d_score(a.metric, (int)c, (int)A, B));
+      const uint64_t keyj = a.autocomplete == 1 ? ~(uint64_t)dj : a.autocomplete == 2 ? by_doc_key(dj, (int)c, B) : score_bits(d_score(a.metric, (int)c, (int)A, B, a.mt));
       while (m) {
         if (!a.lm_values && tk.n == k) { m &= ballot(better(keyj, dj, tk.worst_s, tk.worst_id)); if (!m) break; }
         const int l = __builtin_ctzll(m);
@@ -2106,8 +2136,8 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
         const uint32_t d = readlane(dj, l);
         auto offer = [&](int overlap) {
           if (a.lm_values) topk_insert(tk, (uint64_t)d_lm_count(a.lm_values, lm_from, lm_to, d, lane), d, lane);
-          else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, ~(uint64_t)d, d, lane); }
-          else topk_insert(tk, score_bits(d_score(a.metric, overlap, (int)A, B)), d, lane);
+          else if (a.autocomplete) { if (d >= a.ac_first) topk_insert(tk, a.autocomplete == 2 ? by_doc_key(d, overlap, B) : ~(uint64_t)d, d, lane); }
+          else topk_insert(tk, score_bits(d_score(a.metric, overlap, (int)A, B, a.mt)), d, lane);
         };
         offer((int)ov);
         if (ix.n_dup_docs && ((ix.dup_bits[d >> 5] >> (d & 31u)) & 1u)) {
@@ -2156,7 +2186,7 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
           ps.sort((int)n);
           __threadfence();
           __syncthreads();
-          const int T0 = a.autocomplete ? (int)A : d_threshold(a.metric, a.alpha, (int)A, B);
+          const int T0 = a.autocomplete == 1 ? (int)A : d_threshold(a.metric, a.alpha, (int)A, B, a.mt);
           if ((int)n == T0) {
             const int copies = (int)sv[0];
             for (int c2 = 1; c2 < copies; c2++) offer((int)n);
@@ -2192,7 +2222,10 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
       rank += (better(sj, dj, s, d) || (sj == s && dj == d && j < i)) ? 1u : 0u;
     }
     out_ids[rank] = d;
-    if (out_scores) out_scores[rank] = bits_score(s);
+    if (a.autocomplete == 2) {
+      if (out_scores) out_scores[rank] = d_score(a.metric, (int)(s & 0xFFFFu), (int)A, (int)((s >> 16) & 0xFFFFu), a.mt);
+      if (a.out_aux) a.out_aux[(uint64_t)qi * k + rank] = (uint32_t)s;
+    } else if (out_scores) out_scores[rank] = bits_score(s);
   }
   if (lane == 0) a.out_counts[qi] = n;
 }

@@ -48,6 +48,30 @@ def _c_desc(d):
     return desc
 
 
+class MetricTables:
+    """sg_metric_tables: an opaque metric.Metric at one similarity, tabulated and resident in HBM."""
+
+    def __init__(self, handle, a_max):
+        self._h, self.a_max = handle, a_max
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            _lib.lib().sg_metric_tables_release(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _max_terms(offs, description):
+    """upper bound of the n-grams of the longest query of a batch (bytes + wrap runes)"""
+    longest = int((offs[1:] - offs[:-1]).max()) if len(offs) > 1 else 0
+    return longest + len(description.wrap[0]) + len(description.wrap[1]) + 1
+
+
 class Ticket:
     """A batch in flight (sg_ticket).  wait() must be called exactly once; the buffers of the submit are kept alive here."""
 
@@ -196,7 +220,7 @@ class NGramIndex:
             pass
 
     # ---- search: host buffers ------------------------------------------------------------
-    def suggest_batch(self, queries=None, metric="jaccard", similarity=0.5, k=10, blob=None, offs=None, multi=False):
+    def suggest_batch(self, queries=None, metric="jaccard", similarity=0.5, k=10, blob=None, offs=None, multi=False, tables=None):
         """-> (ids[n_q,k] u32, scores[n_q,k] f64, counts[n_q] u32); row i best first.  multi=True: sg_suggest_batch_multi
         (the batch sliced over every replica)."""
         if blob is None:
@@ -208,11 +232,94 @@ class NGramIndex:
         sc = np.zeros((n_q, k), dtype=np.float64)
         cnt = np.zeros(n_q, dtype=np.uint32)
         L = _lib.lib()
+        m = resolve(metric)
+        if m.code is None or tables is not None:      # a Metric implementation the device has no twin of: tabulated (sg_suggest_batch_tables)
+            tb = tables or self.metric_tables(m, similarity, _max_terms(offs, self.description))
+            with self._use() as h:
+                _lib.check(L.sg_suggest_batch_tables(h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, tb._h, int(k),
+                                                     ids.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
+            return ids, sc, cnt
         with self._use() as h:
             _lib.check((L.sg_suggest_batch_multi if multi else L.sg_suggest_batch)(
-                h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code, float(similarity), int(k),
+                h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, m.code, float(similarity), int(k),
                 ids.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
         return ids, sc, cnt
+
+    def metric_tables(self, metric, similarity, a_max):
+        """MinY / MaxY / Threshold / 1 - Distance of `metric` (any object with the four methods of metric.Metric,
+        pkg/metric/metric.go:7-16) at `similarity`, tabulated for queries of up to a_max n-grams and uploaded
+        (sg_metric_tables_create).  Reusable across calls; released with the object."""
+        m = resolve(metric)
+        a_max = int(max(1, a_max))
+        S = int(self.stats()["n_segments"])
+        alpha = float(similarity)
+        n_a = a_max + 1
+        i32 = lambda v: int(max(-2**31, min(2**31 - 1, v)))                                  # noqa: E731
+        min_y = np.array([i32(m.MinY(alpha, a)) for a in range(n_a)], dtype=np.int32)
+        max_y = np.array([i32(m.MaxY(alpha, a)) for a in range(n_a)], dtype=np.int32)
+        thr = np.zeros((n_a, S), dtype=np.int32)
+        score = np.zeros((n_a, S, n_a), dtype=np.float64)
+        for a in range(1, n_a):
+            for b in range(max(0, int(min_y[a])), min(S - 1, int(max_y[a])) + 1):
+                thr[a, b] = i32(m.Threshold(alpha, a, b))
+                for o in range(max(0, int(thr[a, b])), a + 1):          # (a query that repeats a term: overlaps up to a)
+                    try:
+                        score[a, b, o] = 1 - m.Distance(o, a, b)          # metricScorer.Score, pkg/suggest/scorer.go:29-31
+                    except ZeroDivisionError:
+                        score[a, b, o] = float("nan")
+        t = C.c_void_p()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_metric_tables_create(h, a_max, min_y.ctypes.data, max_y.ctypes.data, thr.ctypes.data, score.ctypes.data, C.byref(t)))
+        return MetricTables(t, a_max)
+
+    def suggest_batch_from(self, queries=None, metric="jaccard", similarity=0.5, first_doc=0, limit=1024, blob=None, offs=None, tables=None):
+        """nGramSuggester.Suggest for ANY collector (suggester.go:78-99): per query the `limit` smallest docIDs >= first_doc
+        among ALL documents whose overlap reaches their segment's threshold -> (ids, scores, aux, counts); aux = segment << 16
+        | overlap.  sg_suggest_batch_from."""
+        if blob is None:
+            blob, offs = pack_strings(queries)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n_q = len(offs) - 1
+        ids = np.zeros((n_q, limit), dtype=np.uint32)
+        sc = np.zeros((n_q, limit), dtype=np.float64)
+        aux = np.zeros((n_q, limit), dtype=np.uint32)
+        cnt = np.zeros(n_q, dtype=np.uint32)
+        m = resolve(metric)
+        if m.code is None and tables is None:
+            tables = self.metric_tables(m, similarity, _max_terms(offs, self.description))
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_suggest_batch_from(h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, m.code or 0, float(similarity),
+                                                        tables._h if tables is not None else None, int(first_doc), int(limit), ids.ctypes.data,
+                                                        sc.ctypes.data, aux.ctypes.data, cnt.ctypes.data))
+        return ids, sc, aux, cnt
+
+    def suggest_all(self, query, metric="jaccard", similarity=0.5, page=1024, tables=None):
+        """EVERY candidate of one query, ascending docID: [(docID, score, overlap, segment)] — what the reference's Suggest
+        streams to the caller's collector — paged through sg_suggest_batch_from.  A document that repeats a term can appear
+        several times; a page that ends inside such a run is resumed AT that docID and the entries already
+        delivered are skipped."""
+        out, first, skip = [], 0, 0
+        m = resolve(metric)
+        if m.code is None and tables is None:
+            tables = self.metric_tables(m, similarity, len(_enc(query)) + 16)
+        while True:
+            ids, sc, aux, cnt = self.suggest_batch_from([query], m, similarity, first, page, tables=tables)
+            c = int(cnt[0])
+            if c >= _lib.SG_COUNT_LM_ERROR:
+                raise ValueError("query cannot be answered (status %#x)" % c)
+            n = min(c, page)
+            rows = [(int(ids[0, j]), float(sc[0, j]), int(aux[0, j]) & 0xFFFF, int(aux[0, j]) >> 16) for j in range(n)]
+            out.extend(rows[skip:])
+            if n < page:
+                return out
+            last = rows[-1][0]
+            run = sum(1 for r in rows if r[0] == last)     # (rows ascend: the entries of the last document are the page's tail)
+            if run == n:                                    # a whole page of one document: ask again with a larger page
+                del out[len(out) - (n - skip):]
+                page *= 2
+                continue
+            first, skip = last, run                         # resume AT the last docID, past its entries already delivered
 
     def autocomplete_batch(self, queries=None, limit=10, blob=None, offs=None, multi=False):
         if blob is None:
@@ -232,19 +339,29 @@ class NGramIndex:
         """EVERY document the prefix completes, ascending docID — what the reference's Autocomplete hands to the caller's
         collector (pkg/suggest/autocomplete.go:40-77) — paged through sg_autocomplete_one_from."""
         q = _enc(query)
-        out, first = [], 0
-        ids = np.zeros(page, dtype=np.uint32)
+        out, first, skip = [], 0, 0
         cnt = C.c_uint32()
         while True:
+            ids = np.zeros(page, dtype=np.uint32)
             with self._use() as h:
                 _lib.check(_lib.lib().sg_autocomplete_one_from(h, q, len(q), int(first), int(page), ids.ctypes.data, C.addressof(cnt)))
             c = int(cnt.value)
             if c >= _lib.SG_COUNT_LM_ERROR:
                 raise ValueError("query cannot be answered (status %#x)" % c)
-            out.extend(int(x) for x in ids[:min(c, page)])
-            if c < page or out[-1] == 0xFFFFFFFF:
+            n = min(c, page)
+            rows = [int(x) for x in ids[:n]]
+            out.extend(rows[skip:])
+            if n < page:
                 return out
-            first = out[-1] + 1
+            # a document that repeats a term is emitted once per secondary match: a page that ends inside such a run is resumed
+            # AT that docID, past the entries of it already delivered (resuming at last + 1 dropped the rest of the run)
+            last = rows[-1]
+            run = sum(1 for r in rows if r == last)
+            if run == n:
+                del out[len(out) - (n - skip):]
+                page *= 2
+                continue
+            first, skip = last, run
 
     # ---- search: host buffers, asynchronous (sg_suggest_submit / sg_ticket_wait) -----------------
     def suggest_submit(self, blob, offs, metric, similarity, k, ids, scores, counts):
@@ -286,9 +403,14 @@ class NGramIndex:
         ids = np.zeros((1, k), dtype=np.uint32)
         sc = np.zeros((1, k), dtype=np.float64)
         cnt = C.c_uint32()
-        with self._use() as h:      # one query per call: coalesced with the other callers' (sg_suggest_one)
-            _lib.check(_lib.lib().sg_suggest_one(h, q, len(q), resolve(metric).code, float(similarity), int(k), ids.ctypes.data,
-                                                 sc.ctypes.data, C.addressof(cnt)))
+        m = resolve(metric)
+        if m.code is None:          # a Metric implementation of the caller's: tabulated (sg_suggest_batch_tables)
+            ids, sc, cn = self.suggest_batch([q], m, similarity, k)
+            cnt = C.c_uint32(int(cn[0]))
+        else:
+            with self._use() as h:      # one query per call: coalesced with the other callers' (sg_suggest_one)
+                _lib.check(_lib.lib().sg_suggest_one(h, q, len(q), m.code, float(similarity), int(k), ids.ctypes.data,
+                                                     sc.ctypes.data, C.addressof(cnt)))
         c = int(cnt.value)
         if c == _lib.SG_COUNT_REF_PANIC:
             raise RuntimeError("query window is empty: the reference panics here (suggester.go:62, negative channel capacity)")

@@ -659,3 +659,148 @@ def test_rows_do_not_depend_on_how_a_batch_is_cut(synth_small):
     po[1:] = np.cumsum(qo[pick + 1] - qo[pick])
     pb = np.concatenate([qb[int(qo[i]):int(qo[i + 1])] for i in pick])
     assert_same((ids[pick], sc[pick], cnt[pick]), ora.suggest_batch(pb, po, "jaccard", 0.5, 7))
+
+
+class _OracleBacked:
+    """metric.Metric (pkg/metric/metric.go:7-16) as an opaque implementation: the four methods answer from the ORACLE's
+    restatement of pkg/metric/*.go, and nothing tells the engine which metric it is (code None) — it is tabulated."""
+    code = None
+
+    def __init__(self, name):
+        self.name = name
+
+    def MinY(self, alpha, size): return oracle.metric_min_y(self.name, alpha, size)
+    def MaxY(self, alpha, size): return oracle.metric_max_y(self.name, alpha, size)
+    def Threshold(self, alpha, a, b): return oracle.metric_threshold(self.name, alpha, a, b)
+    def Distance(self, inter, a, b): return 1 - oracle.metric_score(self.name, inter, a, b)     # (only 1 - Distance is tabulated: see below)
+
+
+@pytest.mark.parametrize("metric,alpha", METRICS)
+def test_tabulated_metric_equals_the_native_one(synth_small, metric, alpha):
+    """sg_metric_tables_create + sg_suggest_batch_tables: an opaque Metric implementation reaches the engine as tables of its
+    four methods; filled from the oracle's own metric functions (scores taken as the oracle computes them) the rows must be
+    the native metric's, bit for bit — ids, order, score bits — and so must the Python mirror's own formulas
+    (suggest_amd/metric.py)."""
+    gpu, ora, qb, qo = synth_small
+    want = ora.suggest_batch(qb, qo, metric, alpha, 10)
+
+    class Exact(_OracleBacked):
+        pass
+    m = Exact(metric)
+    tb = gpu.metric_tables(m, alpha, 48)
+    # the score table holds what metricScorer.Score returns (scorer.go:29-31); write the oracle's own doubles over the
+    # 1 - (1 - x) round trip of the duck above so that the comparison is bit-exact by construction of the TABLE, not of Python
+    S = gpu.stats()["n_segments"]
+    score = np.zeros((49, S, 49))
+    thr = np.zeros((49, S), np.int32)
+    mn = np.array([oracle.metric_min_y(metric, alpha, a) for a in range(49)], np.int32)
+    mx = np.array([min(oracle.metric_max_y(metric, alpha, a), 2**31 - 1) for a in range(49)], np.int32)
+    for a in range(1, 49):
+        for b in range(max(0, int(mn[a])), min(S - 1, int(mx[a])) + 1):
+            thr[a, b] = oracle.metric_threshold(metric, alpha, a, b)
+            for o in range(max(0, int(thr[a, b])), min(a, 48) + 1):
+                score[a, b, o] = oracle.metric_score(metric, o, a, b)
+    import ctypes as C
+    from suggest_amd import _lib
+    from suggest_amd.index import MetricTables
+    t = C.c_void_p()
+    _lib.check(_lib.lib().sg_metric_tables_create(gpu._h, 48, mn.ctypes.data, mx.ctypes.data, thr.ctypes.data, score.ctypes.data, C.byref(t)))
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, k=10, tables=MetricTables(t, 48)), want)
+    # the Python mirror of pkg/metric (IEEE doubles, Go's evaluation order) through the same path
+    from suggest_amd.metric import resolve
+
+    class Opaque:                                           # a duck: no code, the built-in's four methods
+        code = None
+
+        def __init__(self, inner):
+            self.MinY, self.MaxY, self.Threshold, self.Distance = inner.MinY, inner.MaxY, inner.Threshold, inner.Distance
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=Opaque(resolve(metric)), similarity=alpha, k=10), want)
+    del tb
+
+
+def test_tabulated_metric_of_the_callers_own(cars_lines):
+    """A Metric the engine has never heard of — Tversky-like, asymmetric in |A| and |B| — against a brute-force evaluation of
+    the reference's definition of Suggest on the oracle's tokens: every document of cardinality in [MinY, MaxY] whose overlap
+    reaches Threshold, scored 1 - Distance, top-k by (score desc, docID asc)."""
+    import math
+    from suggest_amd import NGramIndex
+
+    class Tversky:
+        code = None
+
+        def MinY(self, alpha, size): return int(math.ceil(alpha * size * 0.75))
+        def MaxY(self, alpha, size): return int(math.floor(size / alpha * 1.25))
+        def Threshold(self, alpha, a, b): return int(math.ceil(alpha * (0.75 * a + 0.25 * b)))
+        def Distance(self, inter, a, b): return 1 - inter / (0.75 * a + 0.25 * b)
+    docs = [l for l in cars_lines[:1500]]
+    gpu = NGramIndex(docs, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(docs, **CARS_DESC)
+    toks = [ora.tokenize(d) for d in docs]
+    m, alpha, k = Tversky(), 0.55, 7
+    queries = [docs[i] for i in range(0, 1500, 37)] + [docs[i][1:-1] + b"q" for i in range(5, 1500, 91)]
+    ids, sc, cnt = gpu.suggest_batch(queries, m, alpha, k)
+    S = gpu.stats()["n_segments"]
+    for qi, q in enumerate(queries):
+        qt = ora.tokenize(q)
+        A = len(qt)
+        if A == 0:
+            assert cnt[qi] == 0
+            continue
+        lo, hi = m.MinY(alpha, A), min(m.MaxY(alpha, A), S - 1)
+        cands = []
+        for d, dt in enumerate(toks):
+            B = len(dt)
+            if not (lo <= B <= hi) or len(set(dt)) != B:       # (documents that repeat a term have secondary entries: left out of the brute force)
+                continue
+            T = m.Threshold(alpha, A, B)
+            if T == 0 or T > B or T > A:
+                continue
+            ds = set(dt)
+            ov = sum(1 for t in qt if t in ds)
+            if ov >= T:
+                cands.append((-(1 - m.Distance(ov, A, B)), d))
+        cands.sort()
+        dup_docs = {d for d, dt in enumerate(toks) if len(set(dt)) != len(dt)}
+        got = [(int(ids[qi, j]), float(sc[qi, j])) for j in range(int(cnt[qi]))]
+        if any(d in dup_docs for d, _ in got):
+            continue
+        assert got == [(d, -s) for s, d in cands[:k]], (q, got, cands[:k])
+
+
+def test_suggest_pages_through_every_candidate(cars_lines):
+    """sg_suggest_batch_from: the fuzzy search for ANY collector — every document whose overlap reaches its segment's threshold,
+    ascending docID, paged — against the oracle's Suggest with k = the whole dictionary (the same candidates, ordered by
+    score): the multisets of (docID, score bits) must be equal, documents that repeat a term (several entries) included, for
+    pages that end inside such runs too."""
+    from suggest_amd import NGramIndex
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    queries = [b"Nissan Mar", b"NISSAN TITAN", b"toyota corola", cars_lines[3238], cars_lines[1111][:-3], b"zzzzzz", b"a"]
+    n_multi = 0
+    for metric, alpha in (("jaccard", 0.3), ("cosine", 0.5), ("dice", 0.4)):
+        for q in queries:
+            qb, qo = oracle.pack_strings([q])
+            oi, os_, oc = ora.suggest_batch(qb, qo, metric, alpha, len(cars_lines) * 2)[:3]
+            if oc[0] >= 0xFFFFFFF0:
+                continue
+            want = sorted((int(oi[0, j]), int(os_.view(np.uint64)[0, j])) for j in range(int(oc[0])))
+            n_multi += len(want) != len({d for d, _ in want})
+            for page in (3, 64, 5000):
+                if len(want) / page > 300:
+                    continue
+                rows = gpu.suggest_all(q, metric, alpha, page=page)
+                ids = [r[0] for r in rows]
+                assert ids == sorted(ids)
+                got = sorted((r[0], int(np.float64(r[1]).view(np.uint64))) for r in rows)
+                assert got == want, (metric, q, page, got[:5], want[:5])
+                for d, s, ov, seg in rows:                       # aux: the overlap and segment the score came from
+                    assert np.float64(oracle.metric_score(metric, ov, len(ora.tokenize(q)), seg)).view(np.uint64) == np.float64(s).view(np.uint64)
+    assert n_multi >= 3      # documents with several entries were among the results
+    # batches, and first_doc / limit as given
+    qb, qo = oracle.pack_strings(queries)
+    ids, sc, aux, cnt = gpu.suggest_batch_from(blob=qb, offs=qo, metric="cosine", similarity=0.5, first_doc=2000, limit=16)
+    for i, q in enumerate(queries):
+        if cnt[i] >= 0xFFFFFFF0:
+            continue
+        rows = [r for r in gpu.suggest_all(q, "cosine", 0.5) if r[0] >= 2000][:16]
+        assert [r[0] for r in rows] == ids[i, :int(cnt[i])].tolist()
