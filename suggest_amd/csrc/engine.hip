@@ -21,6 +21,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -872,8 +873,13 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // kTight = true: threshold tightening (see d_tighten) — pays where queries have many more matches than k (real
 // dictionaries: cars +19 %, words +38 %) and costs the others ~4 % in registers, so it is its own instantiation too; the
 // host picks per launch from the share of recent queries whose top-k filled (fill_stat).
-template <bool kParts, bool kLM, bool kTight, bool kSlim>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
+// kW4 = true: compiled for FOUR waves per SIMD (128 VGPRs: ~30 values of the cold paths go to scratch, the stream loop's
+// blocks stay clean — tests/test_kernel_resources.py).  Sixteen wavefronts per CU instead of twelve, for launches whose LDS
+// footprint lets sixteen in (10 240 B each: the slim tables with 2^10 counter words): the short-list workloads — a
+// spellchecker's vocabulary, the reference's own dictionaries, 1 M strings — are bound by dependent memory round trips
+// (tile, first rows of a group, forward index), not by the stream, and more wavefronts are what hides those.
+template <bool kParts, bool kLM, bool kTight, bool kSlim, bool kW4 = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kW4 ? 4 : 3, kW4 ? 4 : 3))) void sg_search_kernel_t(const BatchArgs a) {
   using L = Lds<kSlim>;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
@@ -2278,7 +2284,7 @@ struct SpellArgs {
   uint8_t* status;               // [n_q] out: 0 scorer, 1 nil scorer, 2 error
   const uint32_t* a_ids; const uint32_t* a_cnt;   // autocomplete rows [n_q][top_k]
   const uint32_t* f_ids; const uint32_t* f_cnt;   // fuzzy rows [n_q][top_k] (rows of the selected queries only)
-  uint32_t* sel; uint32_t* sel_n;
+  uint8_t* sel_flag;                              // [n_q] 1: the query's completion list is short, it gets the fuzzy search
   uint32_t* out_ids; uint32_t* out_counts;        // [n_q][top_k + 1]
   // ---- spell_tokenize_kernel: the word tokeniser and the word ids, on the device ----
   const uint8_t* q_blob; const uint64_t* q_offs;  // the queries
@@ -2419,11 +2425,12 @@ __global__ void spell_next_kernel(const SpellArgs p) {
   p.lm_from[i] = from; p.lm_to[i] = to; p.status[i] = (uint8_t)st;
 }
 
+// (a flag per query: the fuzzy launch makes its own list of the flagged ones, longest last word first — query_order_*)
 __global__ void spell_select_kernel(const SpellArgs p) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n_q) return;
   const uint32_t c = p.a_cnt[i];
-  if (p.has_word[i] && c != SG_COUNT_TOO_LONG && c < p.top_k) p.sel[atomicAdd(p.sel_n, 1u)] = i;
+  p.sel_flag[i] = (p.has_word[i] && c != SG_COUNT_TOO_LONG && c < p.top_k) ? 1 : 0;
 }
 
 // one wavefront per query: at most 2 * top_k candidates
@@ -2487,6 +2494,8 @@ __global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
 // a run behind the lengths before it and scatters its queries there.  Which of two equally long queries comes first is
 // left to the atomics; rows are written by query index, so the results do not depend on it.
 // ctl: [0] = n_q (BatchArgs::q_sel_n), [4 .. 260) histogram, [260 .. 516) cursors — zeroed by the host before (1).
+// `flag` non-null: only the queries it marks are listed (a launch over a subset of the batch: Predict's fuzzy top-up, whose
+// subset used to run in the order the selection's atomics left — long words, the heavy ones, anywhere), and ctl[0] = how many.
 #define SG_ORDER_CTL_WORDS 516
 __device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, const uint32_t* q_len, uint32_t i, int shortest_first) {
   const uint32_t len = q_len ? min(q_len[i], 255u) : (uint32_t)min((unsigned long long)(q_offs[i + 1] - q_offs[i]), 255ull);
@@ -2494,30 +2503,37 @@ __device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, const ui
   if (q_len && len == 0u) return 255u;
   return shortest_first ? len : 255u - len;
 }
-__global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* ctl) {
+__global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* ctl,
+                                                                  const uint8_t* flag) {
   __shared__ uint32_t hist[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
   __syncthreads();
-  if (i < n_q) atomicAdd(&hist[d_order_bin(q_offs, q_len, i, shortest_first)], 1u);
+  if (i < n_q && (!flag || flag[i])) atomicAdd(&hist[d_order_bin(q_offs, q_len, i, shortest_first)], 1u);
   __syncthreads();
   if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
   if (i == 0u) ctl[0] = n_q;
 }
-__global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl) {
+__global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl,
+                                                                    const uint8_t* flag) {
   __shared__ uint32_t hist[256], start[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
   __syncthreads();
-  const uint32_t bin = i < n_q ? d_order_bin(q_offs, q_len, i, shortest_first) : 0u;
-  if (i < n_q) atomicAdd(&hist[bin], 1u);
+  const bool mine = i < n_q && (!flag || flag[i]);
+  const uint32_t bin = mine ? d_order_bin(q_offs, q_len, i, shortest_first) : 0u;
+  if (mine) atomicAdd(&hist[bin], 1u);
   if (tid < 256u) start[tid] = ctl[4 + tid];
   __syncthreads();
-  if (tid == 0u) { uint32_t run = 0; for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = start[b]; start[b] = run; run += c; } }
+  if (tid == 0u) {
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = start[b]; start[b] = run; run += c; }
+    if (flag && blockIdx.x == 0u) ctl[0] = run;               // the subset's size (nobody reads ctl[0] before the search launch)
+  }
   __syncthreads();
   if (tid < 256u) { const uint32_t c = hist[tid]; hist[tid] = c ? start[tid] + atomicAdd(ctl + 260 + tid, c) : 0u; }
   __syncthreads();
-  if (i < n_q) order[atomicAdd(&hist[bin], 1u)] = i;
+  if (mine) order[atomicAdd(&hist[bin], 1u)] = i;
 }
 
 // test hook (sg_debug_pairsort): the device's restatement of Go 1.14 sort.Sort on arbitrary keys — a differential fuzz
@@ -2540,6 +2556,8 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
 #define sg_parts_kernel_tight sg_search_kernel_t<true, false, true, false>
 #define sg_lm_kernel sg_search_kernel_t<false, true, false, false>
 #define sg_lm_kernel_slim sg_search_kernel_t<false, true, false, true>
+#define sg_search_kernel_slim_w4 sg_search_kernel_t<false, false, false, true, true>
+#define sg_lm_kernel_slim_w4 sg_search_kernel_t<false, true, false, true, true>
 
 }  // namespace sg
 

@@ -776,6 +776,9 @@ def test_suggest_pages_through_every_candidate(cars_lines):
     gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
     ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
     queries = [b"Nissan Mar", b"NISSAN TITAN", b"toyota corola", cars_lines[3238], cars_lines[1111][:-3], b"zzzzzz", b"a"]
+    # ... and dictionary lines that repeat a term (the reference returns such a document more than once)
+    rep = [l for l in cars_lines if len(ora.tokenize(l)) != len(set(ora.tokenize(l)))]
+    queries += rep[:3] + rep[len(rep) // 2:len(rep) // 2 + 3]
     n_multi = 0
     for metric, alpha in (("jaccard", 0.3), ("cosine", 0.5), ("dice", 0.4)):
         for q in queries:
