@@ -228,6 +228,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         step(i % n_b)
         gather(i % n_b)
     env.barrier()
+    ls0 = index.launch_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t_start = time.perf_counter()
     for i in range(steps):
@@ -238,6 +239,11 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     env.barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    ls1 = index.launch_stats()
+    d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 32)
+    # bytes the PACKED algorithm has to move per launch: 16 B x the chunks of the lists the kernel streams (the k longest are
+    # skipped, 7 postings per chunk), from the kernel's own count over its sampled queries (one in 32), + queries in + rows out
+    model_bytes = (d_c / d_s * n_q * 16 + float(np.mean([len(b[0]) for b in batches])) + 12.0 * k * n_q) if d_s else None
     alg_timed = float(np.mean([alg[i % n_b] for i in range(steps)]))       # algorithmic bytes per launch, timed launches
     t = torch.tensor([elapsed], dtype=torch.float64)
     per_rank = None
@@ -425,12 +431,16 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             "traffic": traffic, "traffic_source": traffic_src,
             "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBS,
             "traffic_over_algorithmic": traffic / alg_timed if traffic else None,
+            "model_bytes": model_bytes, "traffic_over_model": traffic / model_bytes if traffic and model_bytes else None,
             "kernel": "sg_search_kernel_t", "kernel_ms_avg": avg_ms,
             "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
             "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
             "note": "achieved/frac = measured HBM bytes per launch (PMC) / kernel time: the physical fraction of the 8 TB/s peak. "
                     "effective_* = algorithmic (ScanCount-volume, SURVEY.md 8d) bytes / the same time: list skipping and the compressed "
                     "posting store read less than that volume, so it may exceed the peak and is not a bandwidth. "
+                    "model_bytes = what the packed algorithm must move: 16 B x the chunks of the streamed lists (counted by the kernel over "
+                    "its sampled queries) + queries in + 12 B x k rows out; traffic / model_bytes = what is read on top of that "
+                    "(forward-index records of verified candidates, seg_off rows, term table, dead lanes' lines). "
                     "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
                     "queries, the tokeniser launch (sg_terms_kernel) and the two query-ordering launches (~10 us) before it"}
     rec = {

@@ -272,6 +272,11 @@ typedef struct sg_stats {
 } sg_stats;
 int sg_index_stats(const sg_index* index, sg_stats* out);
 
+/* Sampled counters the fuzzy launches of the primary replica leave (cumulative, each wrapping at 2^32): out[0] sampled queries
+ * whose top-k ended full, [1] sampled queries, [2] their results, [3] the 16-byte chunks of the packed posting store they
+ * streamed — what bench.py's roofline.model_bytes is made of.  Synchronises the device. */
+int sg_index_launch_stats(sg_index* index, uint64_t out[4]);
+
 /* The forward index (doc -> distinct terms) of the primary replica, copied back for documents
  * first .. first+n-1: out_card[i] = cardinality, out_n[i] = number of distinct terms, out_keys[i*cap ..] their term keys. */
 int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, uint32_t* out_card, uint32_t* out_n,

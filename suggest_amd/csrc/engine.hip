@@ -178,7 +178,7 @@ struct BatchArgs {
   // ---- the tokeniser as a launch of its own (sg_terms_kernel, big batches): the search kernel then starts from the term ids ----
   int32_t* pre_A;         // [n_q] d_tokenize's result per query (null: the search kernel tokenises itself)
   uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
-  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results}: cumulative
+  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results, 16-byte chunks of postings they streamed}: cumulative
   uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
@@ -873,13 +873,8 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // kTight = true: threshold tightening (see d_tighten) — pays where queries have many more matches than k (real
 // dictionaries: cars +19 %, words +38 %) and costs the others ~4 % in registers, so it is its own instantiation too; the
 // host picks per launch from the share of recent queries whose top-k filled (fill_stat).
-// kW4 = true: compiled for FOUR waves per SIMD (128 VGPRs: ~30 values of the cold paths go to scratch, the stream loop's
-// blocks stay clean — tests/test_kernel_resources.py).  Sixteen wavefronts per CU instead of twelve, for launches whose LDS
-// footprint lets sixteen in (10 240 B each: the slim tables with 2^10 counter words): the short-list workloads — a
-// spellchecker's vocabulary, the reference's own dictionaries, 1 M strings — are bound by dependent memory round trips
-// (tile, first rows of a group, forward index), not by the stream, and more wavefronts are what hides those.
-template <bool kParts, bool kLM, bool kTight, bool kSlim, bool kW4 = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kW4 ? 4 : 3, kW4 ? 4 : 3))) void sg_search_kernel_t(const BatchArgs a) {
+template <bool kParts, bool kLM, bool kTight, bool kSlim>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
   using L = Lds<kSlim>;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
@@ -1032,6 +1027,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kW4 ? 4 : 3,
   const bool tiny = ix.n_docs <= max_buckets;
 
   uint32_t pushed = 0;                                         // parts of this query queued for the second launch
+  uint32_t q_chunks = 0;                                       // 16-byte chunks of postings streamed for this query (sampled into fill_stat[3])
   for (int tb = b_min; tb <= b_max; tb += wt_max) {
     const int Wt = min(wt_max, b_max - tb + 1);
     const uint32_t stride = (uint32_t)Wt + 1;
@@ -1517,6 +1513,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kW4 ? 4 : 3,
         while (lg < lg_max && (1u << lg) < need) lg++;
       }
       DBG_COUNT(0, 1)
+      q_chunks += Leff;                                          // (what this query streams: the accounting of bench.py's roofline.model_bytes)
       bool saturated = false, overflow = false;
       // the group's streamed lists as a mask over query positions (what `later` in flush_queue is asked against); candidates
       // wait in the queue across groups — up to SG_EPOCHS of them — so the masks of the recent groups are kept in a ring
@@ -1898,6 +1895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kW4 ? 4 : 3,
     atomicAdd(a.fill_stat + 1, 1u);
     if (n == k) atomicAdd(a.fill_stat, 1u);
     if (n) atomicAdd(a.fill_stat + 2, n);
+    atomicAdd(a.fill_stat + 3, q_chunks);
   }
   if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 3] = qi; }
   PH(7)
@@ -2503,8 +2501,13 @@ __device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, const ui
   if (q_len && len == 0u) return 255u;
   return shortest_first ? len : 255u - len;
 }
+// blk_hist non-null (batches of at most SG_ORDER_DIRECT_BLOCKS blocks): (1) also leaves every block's own histogram, and (2)
+// takes a block's run of a length from the blocks before it — a sum of coalesced loads instead of an atomic per block and
+// length on 256 hot words (64 blocks x ~40 lengths: 51 us of a 65 536-query batch's step, now ~10).  Larger batches keep the
+// atomics (the sums would grow with the square of the blocks).
+#define SG_ORDER_DIRECT_BLOCKS 128u
 __global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* ctl,
-                                                                  const uint8_t* flag) {
+                                                                  const uint8_t* flag, uint32_t* blk_hist) {
   __shared__ uint32_t hist[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
@@ -2512,10 +2515,11 @@ __global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t*
   if (i < n_q && (!flag || flag[i])) atomicAdd(&hist[d_order_bin(q_offs, q_len, i, shortest_first)], 1u);
   __syncthreads();
   if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
+  if (blk_hist && tid < 256u) blk_hist[blockIdx.x * 256u + tid] = hist[tid];
   if (i == 0u) ctl[0] = n_q;
 }
 __global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl,
-                                                                    const uint8_t* flag) {
+                                                                    const uint8_t* flag, const uint32_t* blk_hist) {
   __shared__ uint32_t hist[256], start[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
@@ -2523,17 +2527,41 @@ __global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_
   const bool mine = i < n_q && (!flag || flag[i]);
   const uint32_t bin = mine ? d_order_bin(q_offs, q_len, i, shortest_first) : 0u;
   if (mine) atomicAdd(&hist[bin], 1u);
-  if (tid < 256u) start[tid] = ctl[4 + tid];
+  const uint32_t g = tid < 256u ? ctl[4 + tid] : 0u;          // the whole batch's count of this length
+  uint32_t before = 0;                                         // ... and the blocks' before this one (direct path)
+  if (blk_hist && tid < 256u) for (uint32_t b = 0; b < blockIdx.x; b++) before += blk_hist[b * 256u + tid];
+  if (tid < 256u) start[tid] = g;
   __syncthreads();
-  if (tid == 0u) {
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = start[b]; start[b] = run; run += c; }
-    if (flag && blockIdx.x == 0u) ctl[0] = run;               // the subset's size (nobody reads ctl[0] before the search launch)
+  for (uint32_t off = 1; off < 256u; off <<= 1) {              // inclusive scan over the lengths
+    const uint32_t v = (tid < 256u && tid >= off) ? start[tid - off] : 0u;
+    __syncthreads();
+    if (tid < 256u) start[tid] += v;
+    __syncthreads();
+  }
+  if (flag && blockIdx.x == 0u && tid == 255u) ctl[0] = start[255];   // the subset's size (nobody reads ctl[0] before the search launch)
+  if (tid < 256u) {
+    const uint32_t c = hist[tid], base = start[tid] - g;
+    hist[tid] = blk_hist ? base + before : (c ? base + atomicAdd(ctl + 260 + tid, c) : 0u);
   }
   __syncthreads();
-  if (tid < 256u) { const uint32_t c = hist[tid]; hist[tid] = c ? start[tid] + atomicAdd(ctl + 260 + tid, c) : 0u; }
-  __syncthreads();
   if (mine) order[atomicAdd(&hist[bin], 1u)] = i;
+}
+
+// Result rows -> pinned host memory, written by a kernel (the asynchronous host-buffer path, capi.inc): hipMemcpyAsync
+// device-to-host was seen to block its calling thread for 5-6 ms every fourth or fifth call — whatever the kernel in front of
+// it took — and a pipelined host lost a sixth of the GPU to it; stores from a few wavefronts over PCIe do not involve the
+// runtime's copy path at all.  Three segments in one launch.
+struct HostStoreArgs { const uint4* src[3]; uint4* dst[3]; uint64_t n16[3]; };
+__global__ __launch_bounds__(256) void host_store_kernel(const HostStoreArgs h) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int sgm = 0; sgm < 3; sgm++)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < h.n16[sgm]; i += stride) h.dst[sgm][i] = h.src[sgm][i];
+}
+
+// the sampled fill counters (BatchArgs::fill_stat) -> mapped host memory (see launch())
+__global__ void fill_stat_copy_kernel(const uint32_t* src, uint32_t* dst_host) {
+  if (threadIdx.x < 4u) dst_host[threadIdx.x] = src[threadIdx.x];
 }
 
 // test hook (sg_debug_pairsort): the device's restatement of Go 1.14 sort.Sort on arbitrary keys — a differential fuzz
@@ -2556,8 +2584,6 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
 #define sg_parts_kernel_tight sg_search_kernel_t<true, false, true, false>
 #define sg_lm_kernel sg_search_kernel_t<false, true, false, false>
 #define sg_lm_kernel_slim sg_search_kernel_t<false, true, false, true>
-#define sg_search_kernel_slim_w4 sg_search_kernel_t<false, false, false, true, true>
-#define sg_lm_kernel_slim_w4 sg_search_kernel_t<false, true, false, true, true>
 
 }  // namespace sg
 

@@ -432,6 +432,13 @@ class NGramIndex:
         return [int(ids[0, i]) for i in range(c)]
 
     # ---- introspection ---------------------------------------------------------------------
+    def launch_stats(self):
+        """sampled launch counters (cumulative, mod 2^32): {full, sampled, results, chunks} — sg_index_launch_stats"""
+        out = (C.c_uint64 * 4)()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_launch_stats(h, out))
+        return {"full": int(out[0]), "sampled": int(out[1]), "results": int(out[2]), "chunks": int(out[3])}
+
     def stats(self):
         st = _lib.SgStats()
         with self._use() as h:

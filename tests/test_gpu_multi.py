@@ -197,6 +197,27 @@ def test_bench_self_spawns_two_ranks():
     assert rec["replicas_mode"]["n_gpus"] == 2 and rec["replicas_mode"]["rows_equal_device_run"] is True
 
 
+def test_bench_cfg4_preset_two_ranks_carries_a_roofline():
+    """`python bench.py --config cfg4 --gpus N` is BASELINE config 4's line (q=2, Dice, 16 384 queries per GPU, batch sharded
+    over the node): preset + self-spawn, and at N > 1 — where no PMC pass can run — roofline.traffic / frac come from the
+    committed N = 1 measurement of the same workload, per GPU, labelled as such; per-rank rates and the cost of the optional
+    result gather are reported.  Two ranks on GPU 0, gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SG_BENCH_SINGLE_DEVICE="1", SG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["baseline_config"] == "cfg4" and "q=2" in rec["config"]["workload"]
+    roof = rec["roofline"]
+    assert roof["traffic"] and roof["frac"] and 0 < roof["frac"] < 1 and "N=1 PMC figure" in roof["traffic_source"]
+    pr = rec["config"]["per_rank"]
+    assert pr and pr["min"] > 0 and pr["min"] <= pr["mean"] <= pr["max"]
+    assert abs(rec["value"] - 2 * 16384 * 2 / (rec["ms_per_step"] * 2 * 1e-3)) / rec["value"] < 1e-6      # whole-job rate = all ranks' queries / max time
+    if rec["config"]["rccl_gather_check"]:
+        assert rec["config"]["gather_ms"] and rec["config"]["gather_ms"] > 0
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     n = torch.cuda.device_count()
