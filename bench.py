@@ -610,7 +610,7 @@ def main():
                "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u32 (posting/counter work) + f64 (final score)", "data": "synthetic",
                "config": rec["config"], "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"]}
-        for extra in ("host_buffers", "replicas_mode", "parity_vs_oracle"):
+        for extra in ("host_buffers", "host_buffers_pipelined", "replicas_mode", "parity_vs_oracle"):
             if extra in rec:
                 out[extra] = rec[extra]
         if sub_recs:

@@ -44,6 +44,9 @@ namespace sg {
 #define SG_PPC 7           // postings per 16-byte chunk of the packed store: {u32 first x, 6 x u16 gaps} (packed_store.inc)
 #define SG_X_MASK 0x1FFFFFFFu   // first word of a chunk: x of its first posting | (postings in the chunk - 1) << 29
 #define SG_PAD_GAP 41u          // gap of the padding slots behind a chunk's last posting (packed_store.inc)
+#define SG_PPC8 13         // ... of a dense term's chunk: {u32 first x, 12 x u8 gaps} (packed_store.inc; the term's format = bit 31 of its seg_off entries)
+#define SG_X_MASK8 0x0FFFFFFFu  // first word of such a chunk: x | (postings in the chunk - 1) << 28
+#define SG_G8_FLAG 0x80000000u
 #define SG_SUB 2           // rows counted per LDS round trip: SG_SUB * SG_PPC = 14 atomics issued, one wait
 #define SG_EPOCHS 4           // group passes whose candidates may wait in the queue together (ring of their streamed-list masks + docID ranges)
 #define SG_EPOCH_WORDS 6
@@ -111,6 +114,7 @@ struct DeviceIndex {
   const uint2* fwd_rec;        // [n_docs] indexed by x: {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
   const uint32_t* fwd_terms;   // term ids, a doc's list padded to a whole chunk with 0xFFFFFFFF
   uint32_t n_dups, n_dup_docs, n_extra;
+  uint32_t has_g8;             // some term's lists have 8-bit gaps (bit 31 of its seg_off entries): the launches take the kG8 instantiations
   uint32_t slot_mask, n_na, n_lower;
   uint32_t S, n_terms, q, n_docs;
   uint32_t wrap0[SG_WRAP_MAX], wrap1[SG_WRAP_MAX];
@@ -753,6 +757,21 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint4& v, V& p, int at) {
   return (v.x >> 29) + 1u;
 }
 
+// ... and the SG_PPC8 slots of a dense term's chunk: first x, then twelve 8-bit gaps
+template <class V>
+__device__ __forceinline__ uint32_t decode_chunk8(const uint4& v, V& p, int at) {
+  p[at] = v.x & SG_X_MASK8;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    p[at + 1 + e] = p[at + e] + ((v.y >> (8 * e)) & 0xFFu);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) p[at + 5 + e] = p[at + 4 + e] + ((v.z >> (8 * e)) & 0xFFu);
+#pragma unroll
+  for (int e = 0; e < 4; e++) p[at + 9 + e] = p[at + 8 + e] + ((v.w >> (8 * e)) & 0xFFu);
+  return (v.x >> 28) + 1u;
+}
+
 // Counts SG_SUB rows (a row = up to 64 consecutive 16-byte chunks of ONE posting list, one chunk = SG_PPC postings per
 // lane): one LDS atomic per posting (U8: four u8 counters per word, else one u32 counter per word), issued back to back
 // and waited for once.  live[u] is 1 for lanes inside the list, 0 for lanes past its end (they re-read the list's last
@@ -821,6 +840,35 @@ __device__ __forceinline__ uint64_t count_rows(const uint4 (&v)[SG_SUB], const u
   return ballot(mx >= Tm1);
 }
 
+// ONE row of a dense term (8-bit gaps: SG_PPC8 = 13 postings per lane) — as count_rows, 13 atomics and one wait.
+template <bool U8>
+__device__ __forceinline__ uint64_t count_row8(const uint4& v, uint32_t live, uint32_t amask, uint32_t cbase, uint32_t dummy, uint32_t Tm1,
+                                               u32x16& pp, u32x16& was, uint32_t& mx) {
+  uint32_t old[SG_PPC8];
+  const uint32_t am = live ? amask : 0u;
+  const uint32_t cb = live ? cbase : dummy;
+  uint32_t d = v.x & SG_X_MASK8;
+#pragma unroll
+  for (int e = 0; e < SG_PPC8; e++) {
+    if (e) { const uint32_t w = e <= 4 ? v.y : e <= 8 ? v.z : v.w; d += (w >> (8 * ((e - 1) & 3))) & 0xFFu; }   // (v_add_u32_sdwa BYTE_n)
+    pp[e] = d;
+    lds_u32* w = counter_word(d, am, cb);
+    if (U8) old[e] = __hip_atomic_fetch_add(w, 1u << ((d << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else old[e] = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  uint32_t mu = 0;
+#pragma unroll
+  for (int e = 0; e < SG_PPC8; e++) {
+    uint32_t o = old[e];
+    if (U8) o = __builtin_amdgcn_ubfe(o, pp[e] << 3, 8u);
+    was[e] = o;
+    mu = max(mu, o);
+  }
+  mx = live ? mu : 0u;
+  return ballot(mx >= Tm1);
+}
+
 #ifdef SG_PHASE_TIMING   // tools/phase_timing.py: where do a wavefront's cycles go (s_memtime brackets)
 #define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_last = clock64();
 #define PH(n) { const long long ph_now = clock64(); ph_acc[n] += ph_now - ph_last; ph_last = ph_now; }
@@ -873,8 +921,11 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // kTight = true: threshold tightening (see d_tighten) — pays where queries have many more matches than k (real
 // dictionaries: cars +19 %, words +38 %) and costs the others ~4 % in registers, so it is its own instantiation too; the
 // host picks per launch from the share of recent queries whose top-k filled (fill_stat).
-template <bool kParts, bool kLM, bool kTight, bool kSlim>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_search_kernel_t(const BatchArgs a) {
+// kG8 = true: the index has dense terms with 8-bit gaps (13 postings per chunk; packed_store.inc) — their rows are decoded
+// and counted one at a time (count_row8).  Such an index is a long-list index: 2^12 counter words, 7 wavefronts per CU by
+// the LDS, so these instantiations may take the registers of two wavefronts per SIMD.
+template <bool kParts, bool kLM, bool kTight, bool kSlim, bool kG8>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3, kG8 ? 2 : 3))) void sg_search_kernel_t(const BatchArgs a) {
   using L = Lds<kSlim>;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x;
@@ -1058,18 +1109,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
     }
     cnt[lane] = 0u; cnt[64 + lane] = 0u;                          // (the counters are idle between groups: scratch of the statistics)
+    if (kG8) cnt[128 + lane] = 0u;
     __syncthreads();
     // ---- posting volume and present terms per segment: every lane takes (term, segment) pairs — all 64 lanes busy — and
     //      adds into the segment's two words; lane w then owns segment tb+w ----
     for (uint32_t e = lane; e < (uint32_t)A * stride; e += 64) {
       const uint32_t i = __umul24(e, rcp) >> 20, w = e - __umul24(i, stride);
       if (w < (uint32_t)Wt) {
-        const uint32_t len = rows[e + 1] - rows[e];
-        if (len) { atomicAdd(cnt + w, len); atomicAdd(cnt + 64 + w, 1u); }
+        const uint32_t len = rows[e + 1] - rows[e];             // (kG8: bit 31 of a term's entries is its format — the same in both)
+        if (len) {
+          atomicAdd(cnt + w, len); atomicAdd(cnt + 64 + w, 1u);
+          if (kG8) atomicAdd(cnt + 128 + w, len * ((rows[e] & SG_G8_FLAG) ? (uint32_t)SG_PPC8 : (uint32_t)SG_PPC));   // posting slots
+        }
       }
     }
     __syncthreads();
     const uint32_t seg_vol = cnt[lane], seg_ne = cnt[64 + lane];
+    const uint32_t seg_slots = kG8 ? cnt[128 + lane] : 0u;
     __syncthreads();
     // ---- lane w owns segment tb+w: posting volume, present terms, threshold.  kTight: computed again (for the segments
     //      still to come, w >= w_start) whenever the k-th best score has moved: the thresholds tighten with it. ----
@@ -1184,12 +1240,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int i = r * 64 + lane;
         bool found = false;
         if (i < A) {
-          const uint32_t s0 = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0;
+          const uint32_t s0f = rows[i * stride + w], nch = rows[i * stride + w + 1] - s0f;
+          const bool g8 = kG8 && (s0f & SG_G8_FLAG);
+          const uint32_t s0 = kG8 ? s0f & ~SG_G8_FLAG : s0f, xm = g8 ? SG_X_MASK8 : SG_X_MASK;
           if (nch) {                                             // the last chunk that begins at or before x, then its postings
             const uint32_t* p = ix.postings + (uint64_t)s0 * 4;
             uint32_t lo = 0, hi = nch;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & SG_X_MASK) <= x) lo = mid + 1; else hi = mid; }
-            if (lo) {
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & xm) <= x) lo = mid + 1; else hi = mid; }
+            if (lo && g8) {
+              u32x16 pc;
+              const uint32_t np = decode_chunk8(post4[s0 + lo - 1u], pc, 0);
+#pragma unroll
+              for (int e = 0; e < SG_PPC8; e++) found |= (uint32_t)e < np && pc[e] == x;
+            } else if (lo) {
               u32x8v pc;
               const uint32_t np = decode_chunk(post4[s0 + lo - 1u], pc, 0);
 #pragma unroll
@@ -1419,8 +1482,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int need_T = 0;
     if (seg_valid) {
       const int k = (seg_T > a.t_floor && !DBG_SKIP(8u)) ? min(seg_T - a.t_floor, A - 1) : 0;
-      const uint32_t rem = seg_tot - (uint32_t)((float)seg_tot * (float)k * (1.0f / (float)A));
-      need_T = seg_T - k; need_p = rem * SG_PPC;
+      const uint32_t tot_v = kG8 ? seg_slots : seg_tot;                               // (kG8: posting slots — chunks hold 7 or 13)
+      const uint32_t rem = tot_v - (uint32_t)((float)tot_v * (float)k * (1.0f / (float)A));
+      need_T = seg_T - k; need_p = kG8 ? rem : rem * SG_PPC;
     }
     {   // (every lane takes part in the permute: the table row sits in lanes 0..32)
       const uint32_t bn = buckets_needed_lane(need_p, need_T, m16_lane);
@@ -1428,6 +1492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 
     const uint32_t P_need = wave_scan_incl(seg_need, lane), P_tot = wave_scan_incl(seg_valid ? seg_tot : 0u, lane);
+    const uint32_t P_slots = kG8 ? wave_scan_incl(seg_valid ? seg_slots : 0u, lane) : 0u;      // (kG8: chunks hold 7 or 13 postings)
     // Modes without a score (autocomplete, LM ranking) have nothing to tighten against.
     const bool tightening = kTight && !kLM && !a.autocomplete;
     auto tightened_against = [&]() -> uint64_t { return (uint64_t)tile_state[0] | ((uint64_t)tile_state[1] << 32); };
@@ -1452,17 +1517,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const int fit_len = unfit ? __builtin_ctzll(unfit) : 64;
       const int g1 = g0 + max(1, min(run_len, fit_len)) - 1;
       const uint32_t L = readlane(P_tot, g1) - base_tot;      // 16-byte chunks of the group
+      const uint32_t Lv = kG8 ? readlane(P_slots, g1) - (g0 ? readlane(P_slots, g0 - 1) : 0u) : L;   // its volume: posting slots (kG8), else chunks
       const int Tmin = wave_min_i32((lane >= g0 && lane <= g1) ? seg_T : 0x7FFFFFFF);
       wnext = g1 + 1;
 
       // ---- the group's lists: list i = postings of term i over segments tb+g0 .. tb+g1;
       //      lane i keeps its start chunk and chunk count (round r covers terms 64r .. 64r+63) ----
       uint32_t ls_r[2] = {0, 0}, ln_r[2] = {0, 0};
+      bool g8_r[2] = {false, false};                           // (kG8) the list's term has 8-bit gaps
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const int i = r * 64 + lane;
-        if (r < a_rounds && i < A) { ls_r[r] = rows[i * stride + g0]; ln_r[r] = rows[i * stride + g1 + 1] - ls_r[r]; }
+        if (r < a_rounds && i < A) {
+          ls_r[r] = rows[i * stride + g0]; ln_r[r] = rows[i * stride + g1 + 1] - ls_r[r];
+          if (kG8) { g8_r[r] = (ls_r[r] & SG_G8_FLAG) != 0u; ls_r[r] &= ~SG_G8_FLAG; }
+        }
       }
+      const uint64_t g8_m[2] = {kG8 ? ballot(g8_r[0]) : 0ull, kG8 ? ballot(g8_r[1]) : 0ull};
+      // a list's volume in the unit of Lv
+      const uint32_t lv_r[2] = {kG8 ? ln_r[0] * (g8_r[0] ? (uint32_t)SG_PPC8 : (uint32_t)SG_PPC) : ln_r[0],
+                                kG8 ? ln_r[1] * (g8_r[1] ? (uint32_t)SG_PPC8 : (uint32_t)SG_PPC) : ln_r[1]};
       // ---- skip the longest lists (the pigeonhole behind CPMerge, cp_merge.go:22-31): a doc that is
       //      in >= T of the n lists is in >= T-k of ANY n-k of them, so k lists need not be streamed
       //      if postings are flagged at T-k; the exact overlap always comes from the verification over
@@ -1471,10 +1545,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       //      inside a tier (rank among the tier's lanes by v_mbcnt: no loops). ----
       uint64_t skip_m[2] = {0, 0};
       int Teff = Tmin;
-      uint32_t Leff = L;
+      uint32_t Leff = L, Lveff = Lv;
       if (Tmin > a.t_floor && !DBG_SKIP(8u) && !tiny) {
         const uint32_t n_ne = popc64(ballot(ln_r[0] != 0)) + (a_rounds > 1 ? popc64(ballot(ln_r[1] != 0)) : 0u);
-        const uint32_t th[4] = {L * 2u, L + (L >> 2), L, L >> 1};
+        const uint32_t th[4] = {Lv * 2u, Lv + (Lv >> 2), Lv, Lv >> 1};
         uint64_t pick0 = 0, pick1 = 0;
         int budget = Tmin - a.t_floor;
         auto take = [&](uint32_t x, uint32_t thr, uint64_t& pick) {
@@ -1484,25 +1558,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           pick |= keep;
           budget -= (int)popc64(keep);
         };
-        const uint32_t x0 = ln_r[0] * n_ne;
+        const uint32_t x0 = lv_r[0] * n_ne;
 #pragma unroll
         for (int f = 0; f < 4; f++) {
           if (budget > 0) take(x0, th[f], pick0);
-          if (a_rounds > 1 && budget > 0) take(ln_r[1] * n_ne, th[f], pick1);
+          if (a_rounds > 1 && budget > 0) take(lv_r[1] * n_ne, th[f], pick1);
         }
         if (pick0 | pick1) {
-          const uint32_t sk = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
+          const uint32_t sk = (((pick0 >> lane) & 1ull) ? lv_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? lv_r[1] : 0u);
           const uint32_t skipped = readlane(wave_scan_incl(sk, lane), 63);
           const int k_skip = (int)(popc64(pick0) + popc64(pick1));
-          if (buckets_needed((L - skipped) * SG_PPC, Tmin - k_skip, m16_lane) <= max_buckets) {
-            skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Leff = L - skipped;
+          if (buckets_needed((Lv - skipped) * (kG8 ? 1u : (uint32_t)SG_PPC), Tmin - k_skip, m16_lane) <= max_buckets) {
+            skip_m[0] = pick0; skip_m[1] = pick1; Teff = Tmin - k_skip; Lveff = Lv - skipped;
+            if (kG8) {                                          // (the chunks that go with them: what the query streams is counted in chunks)
+              const uint32_t skc = (((pick0 >> lane) & 1ull) ? ln_r[0] : 0u) + (((pick1 >> lane) & 1ull) ? ln_r[1] : 0u);
+              Leff = L - readlane(wave_scan_incl(skc, lane), 63);
+            } else Leff = Lveff;
           }
         }
       }
       // ---- counter geometry: lossy per-bucket counts are upper bounds of per-doc counts ----
       // u32 counters (cheapest per posting) when they resolve the group, else four u8 counters per
       // word; a u8 counter that nears saturation re-runs the group with u32 counters.
-      const uint32_t need = tiny ? max_buckets : buckets_needed(Leff * SG_PPC, Teff, m16_lane);
+      const uint32_t need = tiny ? max_buckets : buckets_needed(Lveff * (kG8 ? 1u : (uint32_t)SG_PPC), Teff, m16_lane);
       bool u8 = need > cnt_words && Teff <= 200;
       bool exact = tiny && u8;                                   // (the u32 re-run of a saturated group is lossy again)
       // the group's documents are the numbers [x_lo, x_hi): what the read-out below may take for candidates
@@ -1550,7 +1628,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           if (qn + cnt_f > cq_cap || DBG_SKIP(1024u)) { overflow = true; break; }
           DBG_COUNT(3, cnt_f)
           const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = (uint32_t)rowlist[row0 + (uint32_t)(ue >= SG_PPC ? 1 : 0)] | ep_tag; }
+          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = ((uint32_t)rowlist[row0 + (uint32_t)(ue >= SG_PPC ? 1 : 0)] & (kG8 ? 0x7Fu : 0xFFu)) | ep_tag; }
+          qn += cnt_f;
+        }
+      };
+      // the same for ONE counted row of a dense term (count_row8: SG_PPC8 slots, all of row `row`)
+      auto flagged8 = [&](const u32x16& vv, uint32_t live, const u32x16& was, uint32_t mx, uint32_t row, uint32_t Tm1, uint32_t last) {
+        if (u8 && ballot(mx >= 250u)) saturated = true;
+        if (overflow) return;
+        uint32_t any_fl = 0;
+#pragma unroll
+        for (int ue = 0; ue < SG_PPC8; ue++) any_fl |= (ballot(live && was[ue] >= Tm1) ? 1u : 0u) << ue;
+        while (any_fl) {
+          const int ue = __builtin_ctz(any_fl);
+          any_fl &= any_fl - 1u;
+          const bool mine = live && was[ue] >= Tm1 && (uint32_t)ue <= last;
+          const uint64_t m = ballot(mine);
+          if (!m) continue;
+          const uint32_t cnt_f = popc64(m);
+          DBG_COUNT(2, cnt_f)
+          if (qn + cnt_f > cq_cap) { overflow = true; break; }
+          DBG_COUNT(3, cnt_f)
+          const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (mine) { cq_doc[pos] = vv[ue]; cq_jj[pos] = ((uint32_t)rowlist[row] & 0x7Fu) | ep_tag; }
           qn += cnt_f;
         }
       };
@@ -1626,7 +1726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
               for (int i = 0; i < 8; i++) {
                 pos[i] = min(lo + ((hi - lo) * (uint32_t)(i + 1)) / 9u, n ? n - 1u : 0u);
-                val[i] = n ? p[(uint64_t)pos[i] * 4] & SG_X_MASK : 0xFFFFFFFFu;
+                val[i] = n ? p[(uint64_t)pos[i] * 4] & (g8_r[r] ? SG_X_MASK8 : SG_X_MASK) : 0xFFFFFFFFu;
               }
               uint32_t nlo = lo, nhi = hi;
 #pragma unroll
@@ -1685,12 +1785,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const uint32_t R = pr[r] + x;
                 if (R >= w0 && R < w0 + wn) {
                   rowtab2[R - w0] = make_uint2(ls_r[r] + x * 64u, min(64u, ln_r[r] - x * 64u));
-                  rowlist[R - w0] = (uint8_t)(r * 64 + lane);
+                  rowlist[R - w0] = (uint8_t)((r * 64 + lane) | (g8_r[r] ? 0x80 : 0));   // (kG8: bit 7 = rows of 13 postings per chunk)
                 }
               }
             }
           }
-          if (lane < 2 * SG_UNROLL) rowtab2[wn + lane] = make_uint2(0u, 0u);   // dead rows behind the last batch
+          if (lane < 2 * SG_UNROLL) { rowtab2[wn + lane] = make_uint2(0u, 0u); if (kG8) rowlist[wn + lane] = 0; }   // dead rows behind the last batch
           __syncthreads();
           // The row loads are issued and awaited by hand (inline asm): the compiler's own wait-count insertion kept the
           // "wait for this batch only, the next one stays in flight" schedule for a while and then — after an unrelated
@@ -1723,6 +1823,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
               u32x16 pp, was;
               uint32_t mx = 0;
               uint64_t any = 0;
+              if (kG8) {   // rows of dense terms (13 postings per chunk) are counted one at a time; so is a 7-per-chunk row next to one
+                const uint32_t f2 = __builtin_amdgcn_readfirstlane((uint32_t)*(const uint16_t*)(rowlist + row0 + (uint32_t)(SG_SUB * h)));
+                if (f2 & 0x8080u) {
+#pragma unroll
+                  for (int u = 0; u < SG_SUB; u++) {
+                    const uint32_t row = row0 + (uint32_t)(SG_SUB * h + u);
+                    if ((f2 >> (8 * u + 7)) & 1u) {
+                      any = u8 ? count_row8<true>(pv[u], sl[u], amask, cbase, dummy_lane, Tm1, pp, was, mx) : count_row8<false>(pv[u], sl[u], amask, cbase, dummy_lane, Tm1, pp, was, mx);
+                      if (any) flagged8(pp, sl[u], was, mx, row, Tm1, pv[u].x >> 28);
+                    } else {
+                      const uint4 px[SG_SUB] = {pv[u], pv[u]};
+                      const uint32_t lx[SG_SUB] = {sl[u], 0u};
+                      any = u8 ? count_rows<true>(px, lx, amask, cbase, dummy_lane, Tm1, pp, was, mx) : count_rows<false>(px, lx, amask, cbase, dummy_lane, Tm1, pp, was, mx);
+                      if (any) flagged(pp, lx, was, mx, row, Tm1, pv[u].x >> 29, 0u);
+                    }
+                  }
+                  DBG_COUNT(1, 1)
+                  continue;
+                }
+              }
               if (DBG_SKIP(4u)) asm volatile("" :: "v"(pv[0].x), "v"(pv[1].x));
               else any = u8 ? count_rows<true>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx) : count_rows<false>(pv, sl, amask, cbase, dummy_lane, Tm1, pp, was, mx);
               DBG_COUNT(1, 1)
@@ -1769,16 +1889,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int n_outer = exact ? 1 : A;
         for (int i = 0; i < n_outer; i++) {
           uint32_t s = x_lo >> 2, n = ((x_hi + 3u) >> 2) - (x_lo >> 2);      // exact: the counter words of the group's documents
+          bool l8 = false;                                                   // (kG8) a list of 13 postings per chunk
           if (!exact) {
             const int r = (i >> 6) & 1, li = i & 63;
             if (!(((r ? str_m[1] : str_m[0]) >> li) & 1ull)) continue;
             // a document in >= Teff streamed lists has its LAST occurrence in the Teff-th streamed list or later
             if (lists_before++ < Teff - 1) continue;
             s = readlane(r ? ls_r[1] : ls_r[0], li); n = readlane(r ? ln_r[1] : ln_r[0], li);
+            l8 = kG8 && (((r ? g8_m[1] : g8_m[0]) >> li) & 1ull);
           }
           for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t c = c0 + lane;
-            u32x8v pc;
+            typename std::conditional<kG8, u32x16, u32x8v>::type pc;
             uint32_t np = 4u;
             if (exact) {
               const uint32_t word = c < n ? cnt[s + c] : 0u;
@@ -1787,10 +1909,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             } else {
               uint4 v = make_uint4(0, 0, 0, 0);
               if (c < n) v = post4[s + c];
-              np = decode_chunk(v, pc, 0);
+              if constexpr (kG8) np = l8 ? decode_chunk8(v, pc, 0) : decode_chunk(v, pc, 0);
+              else np = decode_chunk(v, pc, 0);
             }
 #pragma nounroll
-            for (int e = 0; e < SG_PPC; e++) {
+            for (int e = 0; e < (l8 ? SG_PPC8 : SG_PPC); e++) {
               const uint32_t d = exact ? (s + c) * 4u + (uint32_t)e : pc[e];
               bool flag = false;
               if (c < n && (uint32_t)e < np) {
@@ -2113,7 +2236,16 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
     for (uint32_t i = 0; i < A; i++) {                           // one posting list per query-term OCCURRENCE
       const uint32_t t = term[i];
       if (t == kNoTerm) continue;
-      const uint32_t c0 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], c1 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u];
+      const uint32_t c0f = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], c1 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u] & ~SG_G8_FLAG;
+      const uint32_t c0 = c0f & ~SG_G8_FLAG;                       // (bit 31: the term's lists have 8-bit gaps, packed_store.inc)
+      if (c0f & SG_G8_FLAG) {
+        for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += 64) {
+          u32x16 pc;
+          const uint32_t np = decode_chunk8(((const uint4*)ix.postings)[c], pc, 0);
+#pragma unroll
+          for (int e = 0; e < SG_PPC8; e++) if ((uint32_t)e < np) atomicAdd(cnt + (pc[e] - x0), 1u);
+        }
+      } else
       for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += 64) {
         u32x8v pc;
         const uint32_t np = decode_chunk(((const uint4*)ix.postings)[c], pc, 0);
@@ -2155,15 +2287,18 @@ __device__ void long_query(const BatchArgs& a, uint32_t qi, uint8_t* slot, int l
             uint32_t len = 0, mult = 0;
             if (i < A && term[i] != kNoTerm) {
               const uint32_t t = term[i];
-              const uint32_t c0 = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], nch = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u] - c0;
+              const uint32_t c0f = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B], nch = ix.seg_off[(uint64_t)t * S1 + (uint32_t)B + 1u] - c0f;
+              const uint32_t c0 = c0f & ~SG_G8_FLAG;
+              const bool l8 = (c0f & SG_G8_FLAG) != 0u;
               present = nch != 0u;
               if (present) {
                 bool has = false;
                 {
                   const uint32_t* p = ix.postings + (uint64_t)c0 * 4;
                   uint32_t lo = 0, hi = nch;
-                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & SG_X_MASK) <= x) lo = mid + 1; else hi = mid; }
-                  if (lo) { u32x8v pc; const uint32_t np = decode_chunk(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC; e++) has |= (uint32_t)e < np && pc[e] == x; }
+                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((p[(uint64_t)mid * 4] & (l8 ? SG_X_MASK8 : SG_X_MASK)) <= x) lo = mid + 1; else hi = mid; }
+                  if (lo && l8) { u32x16 pc; const uint32_t np = decode_chunk8(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC8; e++) has |= (uint32_t)e < np && pc[e] == x; }
+                  else if (lo) { u32x8v pc; const uint32_t np = decode_chunk(((const uint4*)ix.postings)[c0 + lo - 1u], pc, 0); for (int e = 0; e < SG_PPC; e++) has |= (uint32_t)e < np && pc[e] == x; }
                 }
                 const uint32_t ts = t * (uint32_t)S + (uint32_t)B;
                 len = ix.list_len[ts];
@@ -2577,13 +2712,19 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
   for (uint32_t i = threadIdx.x; i < n; i += 64) out_vals[i] = v[i];
 }
 
-#define sg_search_kernel sg_search_kernel_t<false, false, false, false>
-#define sg_search_kernel_slim sg_search_kernel_t<false, false, false, true>
-#define sg_search_kernel_tight sg_search_kernel_t<false, false, true, false>
-#define sg_parts_kernel sg_search_kernel_t<true, false, false, false>
-#define sg_parts_kernel_tight sg_search_kernel_t<true, false, true, false>
-#define sg_lm_kernel sg_search_kernel_t<false, true, false, false>
-#define sg_lm_kernel_slim sg_search_kernel_t<false, true, false, true>
+#define sg_search_kernel sg_search_kernel_t<false, false, false, false, false>
+#define sg_search_kernel_slim sg_search_kernel_t<false, false, false, true, false>
+#define sg_search_kernel_tight sg_search_kernel_t<false, false, true, false, false>
+#define sg_parts_kernel sg_search_kernel_t<true, false, false, false, false>
+#define sg_parts_kernel_tight sg_search_kernel_t<true, false, true, false, false>
+#define sg_lm_kernel sg_search_kernel_t<false, true, false, false, false>
+#define sg_lm_kernel_slim sg_search_kernel_t<false, true, false, true, false>
+// indexes with 8-bit-gap terms (DeviceIndex::has_g8): the full LDS layout only
+#define sg_search_kernel_g8 sg_search_kernel_t<false, false, false, false, true>
+#define sg_search_kernel_tight_g8 sg_search_kernel_t<false, false, true, false, true>
+#define sg_parts_kernel_g8 sg_search_kernel_t<true, false, false, false, true>
+#define sg_parts_kernel_tight_g8 sg_search_kernel_t<true, false, true, false, true>
+#define sg_lm_kernel_g8 sg_search_kernel_t<false, true, false, false, true>
 
 }  // namespace sg
 

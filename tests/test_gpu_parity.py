@@ -294,6 +294,55 @@ def test_service_disc_driver_golden(reference_tests, golden_dir):
     assert svc.GetDictionaries() == ["cars"]
 
 
+@pytest.mark.parametrize("g8", [0, 1, 2])
+def test_dense_terms_with_8_bit_gaps(monkeypatch, cars_lines, g8):
+    """The packed store keeps the lists of dense terms as {u32 first, 12 x u8 gaps} chunks (13 postings instead of 7;
+    packed_store.inc, knob SG_G8: 0 never, 1 where it saves chunks, 2 every term).  Rows of such lists are decoded and
+    counted by their own code (count_row8, flagged8, the overflow pass, the per-list searches of documents that repeat a
+    term, the long-query kernel), so: bigram dictionaries (every list dense), plain and in near-duplicate families (queue
+    overflow, ties), with the smallest counter array (docID-range passes cut on the chunks' first words), autocomplete,
+    queries beyond the wavefront kernel's tables, and the reference's cars dictionary with every term forced to the
+    format (gaps above 255 on every other posting: chunks of one or two postings; documents that repeat a term; the
+    one-counter-per-document mode).  The rows never depend on the format."""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    monkeypatch.setenv("SG_G8", str(g8))
+    desc = dict(synth.DESCRIPTION, ngram_size=2)
+    bytes_of = {}
+    for variant, n_docs, log2_cnt in ((dict(), 200000, None), (dict(families=3), 120000, None), (dict(skewed=True), 300000, "9")):
+        if log2_cnt:
+            monkeypatch.setenv("SG_LOG2_CNT", log2_cnt)
+        blob, offs = synth.make_dict(n_docs, seed=41, **variant)
+        qb, qo = synth.make_queries(384, blob, offs, seed=42)
+        gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc))
+        ora = oracle.OracleIndex(blob=blob, offs=offs, **desc)
+        bytes_of[n_docs] = gpu.stats()["device_bytes"]
+        for metric, alpha, k in (("dice", 0.5, 10), ("jaccard", 0.4, 3), ("cosine", 0.3, 100)):
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
+        ids, cnt = gpu.autocomplete_batch(blob=qb, offs=qo, limit=30)
+        oi, oc, _ = ora.autocomplete_batch(qb, qo, 30)
+        assert np.array_equal(cnt, oc)
+        valid = np.arange(30)[None, :] < cnt[:, None]
+        assert np.array_equal(ids[valid], oi[valid])
+        # queries of 150 ... 400 bigrams: sg_long_kernel (ScanCount over the store)
+        rnd = np.random.RandomState(7)
+        long_q = [bytes(rnd.choice(list(b"abcdefghij0123456789"), size=int(n)).astype(np.uint8)) for n in rnd.randint(150, 400, size=6)]
+        lb, lo = oracle.pack_strings(long_q)
+        assert_same(gpu.suggest_batch(blob=lb, offs=lo, metric="dice", similarity=0.2, k=10), ora.suggest_batch(lb, lo, "dice", 0.2, 10), long_q)
+        monkeypatch.delenv("SG_LOG2_CNT", raising=False)
+    if g8 == 0:
+        test_dense_terms_with_8_bit_gaps.plain_bytes = bytes_of
+    elif getattr(test_dense_terms_with_8_bit_gaps, "plain_bytes", None):
+        assert bytes_of[200000] < 0.93 * test_dense_terms_with_8_bit_gaps.plain_bytes[200000]     # the store shrank (postings are ~half of the replica)
+    gpu = NGramIndex(cars_lines, _desc(CARS_DESC))
+    ora = oracle.OracleIndex(cars_lines, **CARS_DESC)
+    queries = list(cars_lines[::3]) + [l[1:] + b"x" for l in cars_lines[::7]]
+    qb, qo = oracle.pack_strings(queries)
+    for tighten in (0, 1):
+        gpu.tune(SG_TIGHTEN=tighten)
+        for metric, alpha, k in [("cosine", 0.5, 5), ("jaccard", 0.2, 100)]:
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k), queries)
+
+
 def test_saturating_bucket_and_candidate_overflow():
     """300 identical documents whose docIDs share their low 12 bits: every posting of a query term lands in the same
     counter bucket (a u8 counter would saturate -> the group is re-run with u32 counters) and the group has far more
