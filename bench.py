@@ -510,10 +510,50 @@ def replicas_measure(env, args, index, w, batches, ids0, cnt0, n_gpus, steps, wa
         ok = ok and np.array_equal(r_cnt[sl], cnt0[b_last]) and np.array_equal(r_ids[sl], ids0[b_last])
     if not ok:
         raise RuntimeError("sg_suggest_batch_multi rows differ from the device-resident run's")
-    return {"value": steps * n_gpus * n_q / dt, "unit": "queries/s", "n_gpus": n_gpus, "devices": index.replicas(), "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "rows_equal_device_run": bool(ok),
-            "note": "ONE process: sg_index_replicate + sg_suggest_batch_multi, %d x %d queries per call from pageable host buffers, "
-                    "a worker thread per replica; PCIe-inclusive (never `value` of the process-per-GPU line)" % (n_gpus, n_q)}
+    rec = {"value": steps * n_gpus * n_q / dt, "unit": "queries/s", "n_gpus": n_gpus, "devices": index.replicas(), "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "rows_equal_device_run": bool(ok),
+           "note": "ONE process: sg_index_replicate + sg_suggest_batch_multi, %d x %d queries per call from pageable host buffers, "
+                   "a worker thread per replica; PCIe-inclusive (never `value` of the process-per-GPU line)" % (n_gpus, n_q)}
+    # ---- the same from ONE host thread over pinned buffers: a ticket per replica (sg_suggest_submit_on), two steps in flight, so
+    #      every GPU's copies run beside its own previous kernel and nothing is staged ----
+    from suggest_amd.index import pinned_array
+    n_b = min(len(batches), 2)
+    slots = []          # [step slot][replica] -> (blob, offs, ids, scores, counts), all pinned
+    for s in range(2):
+        qb, qo = batches[s % n_b]
+        per = []
+        for g in range(n_gpus):
+            pb = pinned_array((max(qb.size, 1),), np.uint8)[:qb.size]; pb[:] = qb
+            po = pinned_array((n_q + 1,), np.uint64); po[:] = qo
+            per.append((pb, po, pinned_array((n_q, k), np.uint32), pinned_array((n_q, k), np.float64), pinned_array((n_q,), np.uint32)))
+        slots.append(per)
+
+    def submit_step(i):
+        return [index.suggest_submit(pb, po, w["metric"], w["similarity"], k, p_ids, p_sc, p_cnt, replica=g)
+                for g, (pb, po, p_ids, p_sc, p_cnt) in enumerate(slots[i % 2])]
+    for i in range(2):
+        for t in submit_step(i):
+            t.wait()
+    p_steps = max(4, steps)
+    t0 = time.perf_counter()
+    pending = []
+    for i in range(p_steps):
+        pending.append(submit_step(i))
+        if len(pending) >= 2:
+            for t in pending.pop(0):
+                t.wait()
+    for ts in pending:
+        for t in ts:
+            t.wait()
+    dt_p = time.perf_counter() - t0
+    ok_p = all(np.array_equal(slots[s][g][4], cnt0[s % n_b]) and np.array_equal(slots[s][g][2], ids0[s % n_b]) for s in range(2) for g in range(n_gpus))
+    if not ok_p:
+        raise RuntimeError("sg_suggest_submit_on rows differ from the device-resident run's")
+    rec["pipelined"] = {"value": p_steps * n_gpus * n_q / dt_p, "unit": "queries/s", "ms_per_step": dt_p / p_steps * 1e3, "steps": p_steps,
+                        "rows_equal_device_run": True,
+                        "note": "ONE host thread: a ticket per replica and step (sg_suggest_submit_on), two steps in flight, pinned buffers "
+                                "(sg_host_alloc): PCIe-inclusive, no staging copy"}
+    return rec
 
 
 def workload_of(args, name):

@@ -188,6 +188,12 @@ void sg_host_free(void* p);
 int sg_suggest_submit(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
                       double similarity, uint32_t k, uint32_t* out_ids, double* out_scores, uint32_t* out_counts,
                       sg_ticket** out_ticket);
+/* ... on replica number `replica` of the index (0 = the primary, in the order of sg_index_replicas): a slice of a batch per GPU
+ * from ONE host thread, no staging copy when the buffers are pinned (the north star's "query batches shard naturally across
+ * the 8 GPUs of one node"; sg_suggest_batch_multi is the synchronous form over pageable buffers). */
+int sg_suggest_submit_on(sg_index* index, uint32_t replica, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
+                         int metric, double similarity, uint32_t k, uint32_t* out_ids, double* out_scores,
+                         uint32_t* out_counts, sg_ticket** out_ticket);
 int sg_autocomplete_submit(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, uint32_t first_doc,
                            uint32_t limit, uint32_t* out_ids, uint32_t* out_counts, sg_ticket** out_ticket);
 int sg_ticket_wait(sg_ticket* ticket);

@@ -24,7 +24,7 @@ EXPORTS = [
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch", "sg_spell_predict_batch_device",
     "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one", "sg_autocomplete_one_from", "sg_autocomplete_batch_from",
     "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort",
-    "sg_host_alloc", "sg_host_free", "sg_suggest_submit", "sg_autocomplete_submit", "sg_ticket_wait",
+    "sg_host_alloc", "sg_host_free", "sg_suggest_submit", "sg_suggest_submit_on", "sg_autocomplete_submit", "sg_ticket_wait",
     "sg_metric_tables_create", "sg_metric_tables_release", "sg_suggest_batch_tables", "sg_suggest_batch_from", "sg_index_launch_stats",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
@@ -122,6 +122,7 @@ def lib():
     if hasattr(L, "sg_host_free"): L.sg_host_free.argtypes = [vp]
     if hasattr(L, "sg_host_free"): L.sg_host_free.restype = None
     if hasattr(L, "sg_suggest_submit"): L.sg_suggest_submit.argtypes = [vp, vp, vp, u32, i32, dbl, u32, vp, vp, vp, C.POINTER(vp)]
+    if hasattr(L, "sg_suggest_submit_on"): L.sg_suggest_submit_on.argtypes = [vp, u32, vp, vp, u32, i32, dbl, u32, vp, vp, vp, C.POINTER(vp)]
     if hasattr(L, "sg_autocomplete_submit"): L.sg_autocomplete_submit.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, C.POINTER(vp)]
     if hasattr(L, "sg_ticket_wait"): L.sg_ticket_wait.argtypes = [vp]
     if hasattr(L, "sg_index_launch_stats"): L.sg_index_launch_stats.argtypes = [vp, vp]

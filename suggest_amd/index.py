@@ -364,17 +364,18 @@ class NGramIndex:
             first, skip = last, run
 
     # ---- search: host buffers, asynchronous (sg_suggest_submit / sg_ticket_wait) -----------------
-    def suggest_submit(self, blob, offs, metric, similarity, k, ids, scores, counts):
+    def suggest_submit(self, blob, offs, metric, similarity, k, ids, scores, counts, replica=0):
         """Enqueues copy in -> search -> copy out for one batch and returns a ticket; `ticket.wait()` blocks until the rows
         are in ids / scores / counts.  All six arrays must stay alive and untouched until then; arrays from `pinned_array`
-        are read / written by the DMA engine directly.  Two tickets in flight hide PCIe behind the kernel."""
+        are read / written by the DMA engine directly.  Two tickets in flight hide PCIe behind the kernel.  `replica`: which
+        replica of the index runs it (0 = the primary) — a slice per GPU from one host thread."""
         n_q = len(offs) - 1
         assert offs.dtype == np.uint64 and blob.dtype == np.uint8 and ids.dtype == np.uint32 and scores.dtype == np.float64 and counts.dtype == np.uint32
         assert ids.size >= n_q * k and scores.size >= n_q * k and counts.size >= n_q
         t = C.c_void_p()
         with self._use() as h:
-            _lib.check(_lib.lib().sg_suggest_submit(h, blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code,
-                                                    float(similarity), int(k), ids.ctypes.data, scores.ctypes.data, counts.ctypes.data, C.byref(t)))
+            _lib.check(_lib.lib().sg_suggest_submit_on(h, int(replica), blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code,
+                                                       float(similarity), int(k), ids.ctypes.data, scores.ctypes.data, counts.ctypes.data, C.byref(t)))
         return Ticket(t, (blob, offs, ids, scores, counts))
 
     def autocomplete_submit(self, blob, offs, limit, ids, counts, first_doc=0):

@@ -44,6 +44,17 @@ def test_replicas_and_multi_dispatch(small):
     assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1])
     tiny = gpu.suggest_batch(blob=qb[:int(qo[3])], offs=qo[:4], metric="cosine", similarity=0.5, k=3, multi=True)   # fewer queries than replicas
     assert_same(tiny, ora.suggest_batch(qb[:int(qo[3])], qo[:4], "cosine", 0.5, 3))
+    # a ticket per replica from one thread (sg_suggest_submit_on): every replica answers like the primary; no fourth one
+    n_q = len(qo) - 1
+    outs = [(np.zeros((n_q, 10), np.uint32), np.zeros((n_q, 10), np.float64), np.zeros(n_q, np.uint32)) for _ in range(3)]
+    tickets = [gpu.suggest_submit(qb, qo, "jaccard", 0.5, 10, *outs[r], replica=r) for r in range(3)]
+    for t in tickets:
+        t.wait()
+    for o in outs:
+        for a, b in zip(one, o):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    with pytest.raises(Exception):
+        gpu.suggest_submit(qb, qo, "jaccard", 0.5, 10, *outs[0], replica=3)
 
 
 def test_coalesced_single_query_callers(small):
@@ -236,6 +247,9 @@ def test_bench_replicas_mode_single_process():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["config"]["pcie_inclusive"] is True and rec["replicas_mode"]["rows_equal_device_run"] is True
+    # ... and the pinned leg: ONE host thread, a ticket per replica and step (sg_suggest_submit_on), two steps in flight
+    piped = rec["replicas_mode"]["pipelined"]
+    assert piped["rows_equal_device_run"] is True and piped["value"] > 0
 
 
 def test_multi_dispatch_over_distinct_devices():
