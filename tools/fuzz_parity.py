@@ -61,6 +61,8 @@ def make_trial(seed, scale=1):
             searches.append((rng.choice(["jaccard", "cosine", "dice"]), rng.choice([0.2, 0.5, 0.8]), rng.choice([1500, 3000])))
     # (drawn after everything else, as above) the tokeniser as a launch of its own — sg_terms_kernel — for batches of >= n queries
     env["SG_PRETOK"] = rng.choice(["0", "1", "1", "2048"])
+    # (round 4, drawn last again) 8-bit gaps for dense terms: 2 = every term (gaps above 255 all over a sparse list: chunks of one posting)
+    env["SG_G8"] = rng.choice(["0", "1", "2", "2"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
