@@ -240,7 +240,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     ls1 = index.launch_stats()
-    d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 32)
+    d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)
     # bytes the PACKED algorithm has to move per launch: 16 B x the chunks of the lists the kernel streams (the k longest are
     # skipped, 7 postings per chunk), from the kernel's own count over its sampled queries (one in 32), + queries in + rows out
     model_bytes = (d_c / d_s * n_q * 16 + float(np.mean([len(b[0]) for b in batches])) + 12.0 * k * n_q) if d_s else None
@@ -631,6 +631,7 @@ def main():
                               "ms_per_step": r["ms_per_step"], "kernel_ms_avg": roof["kernel_ms_avg"],
                               "frac": roof["frac"], "achieved_gbps": roof["achieved"], "traffic": roof["traffic"],
                               "traffic_source": roof["traffic_source"],
+                              "model_bytes": roof.get("model_bytes"), "traffic_over_model": roof.get("traffic_over_model"),
                               "effective_frac": roof["effective_frac"], "effective_gbps": roof["effective_gbps"],
                               "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
                               "bit_exact": (r.get("parity_vs_oracle") or {}).get("bit_exact"),

@@ -278,7 +278,7 @@ typedef struct sg_stats {
 } sg_stats;
 int sg_index_stats(const sg_index* index, sg_stats* out);
 
-/* Sampled counters the fuzzy launches of the primary replica leave (cumulative, each wrapping at 2^32): out[0] sampled queries
+/* Sampled counters the fuzzy launches of the primary replica leave (cumulative; [0..2] wrap at 2^32, [3] is 64 bits wide): out[0] sampled queries
  * whose top-k ended full, [1] sampled queries, [2] their results, [3] the 16-byte chunks of the packed posting store they
  * streamed — what bench.py's roofline.model_bytes is made of.  Synchronises the device. */
 int sg_index_launch_stats(sg_index* index, uint64_t out[4]);

@@ -182,7 +182,7 @@ struct BatchArgs {
   // ---- the tokeniser as a launch of its own (sg_terms_kernel, big batches): the search kernel then starts from the term ids ----
   int32_t* pre_A;         // [n_q] d_tokenize's result per query (null: the search kernel tokenises itself)
   uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
-  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results, 16-byte chunks of postings they streamed}: cumulative
+  uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results, -, u64: 16-byte chunks of postings they streamed}: cumulative
   uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
@@ -1968,8 +1968,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
       a.part_id[(pbase + my_part) * k + i] = tk.id[i];
     }
     if (lane == 0) a.part_n[pbase + my_part] = tk.n;
+    // (what this wavefront streamed of a sampled query: a split query's chunks are the sum over its parts, and only the part
+    //  that merges reaches the accounting at the end)
+    const bool sampled = !kLM && !a.autocomplete && a.fill_stat && (qi & a.fill_mask) == 0u;
     if (!kParts) {                                         // the queued parts all run later: count this one as finished
       if (lane == 0) { a.slot_ctl[2 * qi] = 1u; a.slot_ctl[2 * qi + 1] = pushed + 1u; }
+      if (sampled && lane == 0) atomicAdd((unsigned long long*)(a.fill_stat + 4), (unsigned long long)q_chunks);
       break;
     }
     // release: this part's rows are visible device-wide (across the XCDs' L2s) before it is counted; acquire: the
@@ -1978,7 +1982,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
     if (lane == 0) fin = __hip_atomic_fetch_add(a.slot_ctl + 2 * my_slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     fin = __builtin_amdgcn_readfirstlane(fin);
     const uint32_t n_parts = __builtin_amdgcn_readfirstlane(a.slot_ctl[2 * my_slot + 1]);   // written by the first launch
-    if (fin != n_parts) break;                             // somebody else finishes later and merges
+    if (fin != n_parts) { if (sampled && lane == 0) atomicAdd((unsigned long long*)(a.fill_stat + 4), (unsigned long long)q_chunks); break; }   // somebody else finishes later and merges
     for (uint32_t pp = 0; pp < n_parts; pp++) {
       if (pp == my_part) continue;
       const uint32_t np = __builtin_amdgcn_readfirstlane(a.part_n[pbase + pp]);
@@ -2018,7 +2022,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
     atomicAdd(a.fill_stat + 1, 1u);
     if (n == k) atomicAdd(a.fill_stat, 1u);
     if (n) atomicAdd(a.fill_stat + 2, n);
-    atomicAdd(a.fill_stat + 3, q_chunks);
+    atomicAdd((unsigned long long*)(a.fill_stat + 4), (unsigned long long)q_chunks);
   }
   if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 3] = qi; }
   PH(7)

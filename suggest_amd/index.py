@@ -434,7 +434,7 @@ class NGramIndex:
 
     # ---- introspection ---------------------------------------------------------------------
     def launch_stats(self):
-        """sampled launch counters (cumulative, mod 2^32): {full, sampled, results, chunks} — sg_index_launch_stats"""
+        """sampled launch counters (cumulative; full, sampled, results mod 2^32, chunks 64 bits wide): {full, sampled, results, chunks} — sg_index_launch_stats"""
         out = (C.c_uint64 * 4)()
         with self._use() as h:
             _lib.check(_lib.lib().sg_index_launch_stats(h, out))

@@ -12,7 +12,7 @@ timeout 600 python tools/small_dict_timing.py > $O/${TAG}_small_dictionaries.txt
 timeout 300 python tools/latency.py > $O/${TAG}_latency.txt 2>&1; tail -5 $O/${TAG}_latency.txt
 timeout 900 python tools/fuzz_parity.py --seconds 600 --seed 4242 > $O/${TAG}_fuzz_parity.log 2>&1; tail -1 $O/${TAG}_fuzz_parity.log
 timeout 300 python tools/fuzz_spell.py --seconds 150 --seed 4242 > $O/${TAG}_fuzz_spell.log 2>&1; tail -1 $O/${TAG}_fuzz_spell.log
-timeout 900 bash tools/profile_config.sh $TAG headline --dict-variant skewed --sub-configs none --steps 5 > $O/${TAG}_profile_skewed.log 2>&1; for f in bench kernel_stats traffic; do for e in json csv; do [ -f $O/${TAG}_${f}_headline.$e ] && [ "$f" != "x" ] && true; done; done
+timeout 900 bash tools/profile_config.sh ${TAG}_skewed headline --dict-variant skewed --sub-configs none --steps 5 > $O/${TAG}_profile_skewed.log 2>&1     # (files: <tag>_skewed_*_headline.*)
 cd /tmp; rm -rf /tmp/kt5; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt5 -- python $R/bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline --traffic none > $O/${TAG}_cfg5_trace.log 2>&1
 python $R/tools/kernel_stats.py /tmp/kt5 --skip 3 > $O/${TAG}_kernel_stats_cfg5.csv 2>&1; cut -c1-150 $O/${TAG}_kernel_stats_cfg5.csv | head -8
 cd $R; timeout 900 bash tools/pmc_run.sh ${TAG}_cfg4 --config cfg4 --sub-configs none > $O/${TAG}_pmc_cfg4.txt 2>&1; grep "^search" $O/${TAG}_pmc_cfg4.txt | head -40
