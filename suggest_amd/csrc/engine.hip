@@ -393,6 +393,7 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
                           uint32_t* term, int lane) {
   const DeviceIndex& ix = a.ix;
   const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete == 1 ? 0u : ix.n_wrap1;
+  const AsciiTab tab = d_ascii_tab(ix, lane);           // (asked for up front: its loads travel with the query bytes' instead of behind them)
   // ASCII?
   bool na = false;
   for (uint32_t i = lane; i < qlen; i += 64) {            // one pass over the bytes: ASCII test and, optimistically, the runes
@@ -449,7 +450,6 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
     if (ascii && q_n <= 3u && G <= 64u && ballot(big) == 0) {
       // the common case in registers: a gram of <= 3 ASCII runes is a 21-bit fingerprint, appendUnique
       // (ngram_tokenizer.go:46-54) is G wave-uniform readlanes, normalisation two ds_bpermute per rune
-      const AsciiTab tab = d_ascii_tab(ix, lane);
       const uint32_t g = (uint32_t)lane;
       const bool valid = g < G;
       uint32_t w[3] = {0, 0, 0};
@@ -969,8 +969,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
   const bool primary = !kParts;
   uint32_t qi = blockIdx.x;
   if (!kParts && a.q_sel) {
-    if (qi >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) return;
-    qi = __builtin_amdgcn_readfirstlane(a.q_sel[qi]);
+    // (both loads issued together — the list has an entry for every workgroup of the grid —: one memory round trip at the
+    //  head of every query instead of two)
+    const uint32_t sel_n = *a.q_sel_n, sel_q = a.q_sel[qi];
+    if (qi >= __builtin_amdgcn_readfirstlane(sel_n)) return;
+    qi = __builtin_amdgcn_readfirstlane(sel_q);
   }
   int r_lo = 0, r_hi = 0x7FFFFFFF;                      // segments this wavefront handles (a part of a split query)
   uint32_t my_slot = 0xFFFFFFFFu, my_part = 0;
@@ -1769,7 +1772,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
 #pragma unroll
         for (int r = 0; r < 2; r++) {
           const bool skipped = (skip_m[r] >> lane) & 1ull;
+#ifdef SG_EXP_DROP_TAILS   // (timing experiment only — wrong results: a list's last row is dropped when it is less than half full: what a layout
+                          //  without lanes behind the ends of the lists could gain at best, profiles/r04y_drop_tails.txt)
+          nr[r] = (r < a_rounds && !skipped) ? (ln_r[r] + 31u) >> 6 : 0u;
+#else
           nr[r] = (r < a_rounds && !skipped) ? (ln_r[r] + 63u) >> 6 : 0u;
+#endif
           const uint32_t incl = wave_scan_incl(nr[r], lane);
           pr[r] = n_rows + incl - nr[r];
           n_rows += readlane(incl, 63);
@@ -2048,8 +2056,9 @@ __global__ __launch_bounds__(64) void sg_terms_kernel(const BatchArgs a) {
   const int lane = threadIdx.x;
   uint32_t qi = blockIdx.x;
   if (a.q_sel) {                                             // a launch over a subset of the batch: the same subset
-    if (qi >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) return;
-    qi = __builtin_amdgcn_readfirstlane(a.q_sel[qi]);
+    const uint32_t sel_n = *a.q_sel_n, sel_q = a.q_sel[qi];
+    if (qi >= __builtin_amdgcn_readfirstlane(sel_n)) return;
+    qi = __builtin_amdgcn_readfirstlane(sel_q);
   }
   const uint64_t qb = a.q_offs[qi], qe = a.q_len ? qb + a.q_len[qi] : a.q_offs[qi + 1];
   const int A = d_tokenize(a, a.q_blob + qb, (uint32_t)(qe - qb), s_runes, s_keys, s_term, lane);
@@ -2426,7 +2435,7 @@ struct SpellArgs {
   // ---- spell_tokenize_kernel: the word tokeniser and the word ids, on the device ----
   const uint8_t* q_blob; const uint64_t* q_offs;  // the queries
   uint32_t* ctx_w; uint8_t* ctx_len_w; uint8_t* has_word_w;   // out (what ctx / ctx_len / has_word point at)
-  uint8_t* w_blob; uint64_t* w_off; uint32_t* w_len;          // out: the last word of query i is w_blob[w_off[i] .. + w_len[i]), w_off[i] = 2 * q_offs[i]
+  uint8_t* w_blob; uint64_t* w_off; uint32_t* w_len;          // out: the last word of query i is w_blob[w_off[i] .. + w_len[i]), somewhere in the query's slot w_blob[2 * q_offs[i] .. 2 * q_offs[i + 1])
   const uint2* alpha_ranges; uint32_t n_alpha_ranges;          // the model alphabet's runes >= 128 as inclusive ranges, ascending
   uint64_t alpha_ascii[2];                                     // ... and below 128 as a bitmap
   const uint32_t* lower_from; const uint32_t* lower_to; uint32_t n_lower;   // simple lower-case pairs (the index replica's)
@@ -2458,7 +2467,15 @@ __device__ uint32_t d_word_id(const SpellArgs& p, uint64_t h, const uint8_t* w, 
     if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) {
       const uint32_t o0 = p.vocab_off[e.z], o1 = p.vocab_off[e.z + 1u];
       bool same = o1 - o0 == n;
-      for (uint32_t i = 0; same && i < n; i++) same = p.vocab_bytes[o0 + i] == w[i];
+      // (sixteen bytes per round, their loads issued together: compared one by one with an early exit, a 7-letter word was seven
+      //  dependent memory round trips)
+      for (uint32_t i0 = 0; same && i0 < n; i0 += 16u) {
+        uint8_t vb[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++) vb[j] = i0 + j < n ? p.vocab_bytes[o0 + i0 + j] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++) same = same && (i0 + j >= n || vb[j] == w[i0 + j]);
+      }
       if (same) return e.z;
     }
   }
@@ -2467,69 +2484,133 @@ __device__ uint32_t d_word_id(const SpellArgs& p, uint64_t h, const uint8_t* w, 
 // SpellChecker.Predict's host steps (spellchecker.go:40-64,94-107; language_model.go:100-112), one thread per query: the word
 // tokeniser (strings.ToLower, strings.Trim(" "), maximal runs of alphabet runes — pkg/analysis word tokenizer as the model
 // builds it), the last word, the ids of the words before it (the vocabulary hash, hits confirmed on the bytes), and the
-// wrap / trim rules of LanguageModel.Next.  The last word is written lower-cased into the query's slot of w_blob (two
-// bytes of slot per query byte: a lower-case mapping can lengthen a rune's encoding, 2 -> 3 bytes at most); every token
-// is written there from the slot's start, so what is left at the end is the last one.
-__global__ __launch_bounds__(256) void spell_tokenize_kernel(const SpellArgs p) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.n_q) return;
-  const uint64_t o0 = p.q_offs[i], o1 = p.q_offs[i + 1];
-  const uint8_t* q = p.q_blob + o0;
-  uint32_t a = 0, b = (uint32_t)(o1 - o0);
+// wrap / trim rules of LanguageModel.Next.  The tokens are written lower-cased into the query's slot of w_blob, one behind the
+// other (two bytes of slot per query byte: a lower-case mapping can lengthen a rune's encoding, 2 -> 3 bytes at most).
+// [r4] The queries of a block of 256 threads are consecutive in q_blob: the block copies their bytes into LDS with coalesced
+// loads, every thread scans ITS query there and writes its tokens into an LDS image of its slot, and the slots go out
+// coalesced.  Read and written byte by byte in global memory — 64 lanes at 64 addresses 20-odd bytes apart, a dependent
+// load and a store per byte — the kernel took 0.093 ms with four wavefronts per CU resident: a twentieth of a Predict step.
+#define SG_STOK_BYTES 12288u     // query bytes a block stages (48 per query on average); a block above it keeps the global path
+// One query.  The scan only RECORDS its tokens — where their lower-cased bytes went in the slot, how long they are, their
+// hash — for the first eight and, in a ring of eight, the latest ones; the vocabulary lookups of the context words follow in
+// lockstep over the wave (token t of every lane together).  Looked up where a token ended — a different byte position in
+// every lane — the wave ran d_word_id's chain of dependent loads once per lane and token: most of the kernel's 0.09 ms.
+// Tokens are written one behind the other (the slot has two bytes per query byte), so the last word is wherever it was
+// written: w_off points there.
+__device__ __forceinline__ void spell_tokenize_one(const SpellArgs& p, uint32_t i, const uint8_t* q, uint32_t qlen, uint8_t* slot, uint64_t o0) {
+  uint32_t a = 0, b = qlen;
   while (a < b && q[a] == ' ') a++;                            // (U+0020 is the byte 0x20 and nothing else)
   while (b > a && q[b - 1] == ' ') b--;
-  uint8_t* slot = p.w_blob + 2 * o0;
   const uint32_t N = p.order;
-  uint32_t first[8], last[8];                                  // the first / the last N - 1 context ids (N <= 8)
-  uint32_t n_ctx = 0, n_tok = 0, pending = kUnknownWord;
-  uint32_t wl = 0;                                             // bytes of the token in progress
-  uint32_t last_len = 0;                                       // ... of the last finished one (its bytes stay in the slot until the next starts)
+  uint64_t f_h[8], r_h[8];                                     // hash of token t (t < 8) / of the latest token with index = t mod 8
+  uint32_t f_o[8], f_l[8], r_o[8], r_l[8];                     // its bytes in the slot: offset, length
+  uint32_t n_tok = 0;
+  uint32_t out = 0, start = 0;                                 // bytes written to the slot; where the token in progress begins
   uint64_t h = SG_WORD_HASH_SEED;
+#pragma unroll
+  for (int t = 0; t < 8; t++) { f_h[t] = 0; r_h[t] = 0; f_o[t] = 0; f_l[t] = 0; r_o[t] = 0; r_l[t] = 0; }
   auto end_token = [&]() {
-    if (wl == 0u) return;
-    if (n_tok) {                                               // the token before this one was not the last word: it is context
-      if (n_ctx < 8u) first[n_ctx] = pending;
-      last[n_ctx & 7u] = pending;
-      n_ctx++;
+    if (out == start) return;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      if (n_tok == (uint32_t)t) { f_h[t] = h; f_o[t] = start; f_l[t] = out - start; }
+      if ((n_tok & 7u) == (uint32_t)t) { r_h[t] = h; r_o[t] = start; r_l[t] = out - start; }
     }
-    pending = d_word_id(p, h, slot, wl);
     n_tok++;
-    last_len = wl;
-    wl = 0u;
+    start = out;
   };
   for (uint32_t pos = a; pos < b;) {
     uint32_t adv;
     const uint32_t r = d_lm_lower(p, d_next_rune(q + pos, b - pos, &adv));
     pos += adv;
     if (!d_lm_alpha_has(p, r)) { end_token(); continue; }
-    if (wl == 0u) h = SG_WORD_HASH_SEED;                       // a new token, written from the slot's start
+    if (out == start) h = SG_WORD_HASH_SEED;                   // a new token
     uint8_t enc[4];
     const uint32_t w = d_width(r);
     if (w == 1u) enc[0] = (uint8_t)r;
     else if (w == 2u) { enc[0] = (uint8_t)(0xC0u | (r >> 6)); enc[1] = (uint8_t)(0x80u | (r & 0x3Fu)); }
     else if (w == 3u) { enc[0] = (uint8_t)(0xE0u | (r >> 12)); enc[1] = (uint8_t)(0x80u | ((r >> 6) & 0x3Fu)); enc[2] = (uint8_t)(0x80u | (r & 0x3Fu)); }
     else { enc[0] = (uint8_t)(0xF0u | (r >> 18)); enc[1] = (uint8_t)(0x80u | ((r >> 12) & 0x3Fu)); enc[2] = (uint8_t)(0x80u | ((r >> 6) & 0x3Fu)); enc[3] = (uint8_t)(0x80u | (r & 0x3Fu)); }
-    for (uint32_t j = 0; j < w; j++) { slot[wl + j] = enc[j]; h = d_word_hash_step(h, enc[j]); }
-    wl += w;
+    for (uint32_t j = 0; j < w; j++) { slot[out + j] = enc[j]; h = d_word_hash_step(h, enc[j]); }
+    out += w;
   }
   end_token();
-  p.w_off[i] = 2 * o0;
+  // the last token is the word the searches take; the tokens before it are the context (the id of the last one is never asked for)
+  const uint32_t n_ctx = n_tok ? n_tok - 1u : 0u;
+  uint32_t lw_o = 0, lw_l = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) if (n_tok && ((n_tok - 1u) & 7u) == (uint32_t)t) { lw_o = r_o[t]; lw_l = r_l[t]; }
+  // ids, token t of every lane together.  first[t]: context token t (t < 8).  ring[t]: context token j >= 8 with j mod 8 = t among
+  // the last N - 1 <= 7 context tokens (the only ones of index >= 8 that language_model.go:100-112 can ask for) — r_*[t] still
+  // holds it: the only later token in that ring slot would be j + 8 > n_ctx.
+  uint32_t first[8], ring[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const bool need = (uint32_t)t < n_ctx;
+    first[t] = kUnknownWord;
+    if (__builtin_amdgcn_ballot_w64(need)) { if (need) first[t] = d_word_id(p, f_h[t], slot + f_o[t], f_l[t]); }
+    ring[t] = kUnknownWord;
+  }
+  if (__builtin_amdgcn_ballot_w64(n_ctx > N && n_ctx > 8u)) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const uint32_t j = n_ctx ? (n_ctx - 1u) - (((n_ctx - 1u) - (uint32_t)t) & 7u) : 0u;   // the largest j < n_ctx with j mod 8 = t
+      const bool need = n_ctx > N && j >= 8u && j + (N - 1u) >= n_ctx;
+      if (__builtin_amdgcn_ballot_w64(need)) { if (need) ring[t] = d_word_id(p, r_h[t], slot + r_o[t], r_l[t]); }
+    }
+  }
+  auto id_at = [&](uint32_t j) -> uint32_t {                   // id of context token j (j < 8, or one of the last N - 1)
+    uint32_t v = kUnknownWord;
+#pragma unroll
+    for (int t = 0; t < 8; t++) if ((j & 7u) == (uint32_t)t) v = j < 8u ? first[t] : ring[t];
+    return v;
+  };
+  p.w_off[i] = 2 * o0 + (uint64_t)lw_o;
   p.has_word_w[i] = n_tok ? 1 : 0;
   uint8_t cl = 0;
   uint32_t seq[8];
   uint32_t n_seq = 0;
   if (n_ctx) {                                                 // spellchecker.go:94-107: no context, no scorer
     // language_model.go:100-112
-    if (n_ctx + 1u < N) { seq[n_seq++] = p.start_symbol; for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = first[t]; }
-    else if (n_ctx > N) { for (uint32_t t = n_ctx - (N - 1u); t < n_ctx; t++) seq[n_seq++] = last[t & 7u]; }
-    else if (n_ctx == N) { for (uint32_t t = 0; t + 1u < N; t++) seq[n_seq++] = first[t]; }   // (sic) keeps the FIRST order-1 words
-    else { for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = first[t]; }
+    if (n_ctx + 1u < N) { seq[n_seq++] = p.start_symbol; for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = id_at(t); }
+    else if (n_ctx > N) { for (uint32_t t = n_ctx - (N - 1u); t < n_ctx; t++) seq[n_seq++] = id_at(t); }
+    else if (n_ctx == N) { for (uint32_t t = 0; t + 1u < N; t++) seq[n_seq++] = id_at(t); }   // (sic) keeps the FIRST order-1 words
+    else { for (uint32_t t = 0; t < n_ctx; t++) seq[n_seq++] = id_at(t); }
     if (n_seq == 0u || n_seq >= N) cl = 0xFF;                  // ngram_model.go:65-67: an error
     else cl = (uint8_t)n_seq;
   }
   p.ctx_len_w[i] = cl;
   for (uint32_t t = 0; t < 8u; t++) p.ctx_w[(uint64_t)i * 8u + t] = (cl != 0xFF && t < n_seq) ? seq[t] : 0u;
-  p.w_len[i] = last_len;
+  p.w_len[i] = lw_l;
+}
+__global__ __launch_bounds__(256) void spell_tokenize_kernel(const SpellArgs p) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_in[SG_STOK_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_slot[2 * SG_STOK_BYTES];
+  const uint32_t tid = threadIdx.x, i0 = blockIdx.x * blockDim.x, i = i0 + tid;
+  const uint32_t i1 = min(i0 + (uint32_t)blockDim.x, p.n_q);
+  if (i0 >= p.n_q) return;
+  const uint64_t B0 = p.q_offs[i0], B1 = p.q_offs[i1];          // the block's bytes: uniform
+  const uint32_t nb = (uint32_t)min(B1 - B0, (uint64_t)0xFFFFFFFFu);
+  const bool staged = B1 - B0 <= (uint64_t)SG_STOK_BYTES;
+  uint32_t shift = 0;
+  if (staged) {                                                  // dword loads from the 4-byte boundary at or below the first byte
+    const uintptr_t addr0 = (uintptr_t)(p.q_blob + B0);
+    shift = (uint32_t)(addr0 & 3u);
+    const uint32_t* src = (const uint32_t*)(addr0 - shift);
+    const uint32_t n_dw = (nb + shift + 3u) >> 2;
+    for (uint32_t k = tid; k < n_dw; k += blockDim.x) ((uint32_t*)s_in)[k] = src[k];
+  }
+  __syncthreads();
+  if (i < p.n_q) {
+    const uint64_t o0 = p.q_offs[i], o1 = p.q_offs[i + 1];
+    if (staged) spell_tokenize_one(p, i, s_in + shift + (uint32_t)(o0 - B0), (uint32_t)(o1 - o0), s_slot + 2u * (uint32_t)(o0 - B0), o0);
+    else spell_tokenize_one(p, i, p.q_blob + o0, (uint32_t)(o1 - o0), p.w_blob + 2 * o0, o0);
+  }
+  if (!staged) return;                                           // (uniform)
+  __syncthreads();
+  // the slots out: w_blob + 2 B0 is 2-byte aligned at least (the scratch block is 16-byte aligned)
+  uint16_t* dst = (uint16_t*)(p.w_blob + 2 * B0);
+  for (uint32_t k = tid; k < nb; k += blockDim.x) dst[k] = ((const uint16_t*)s_slot)[k];
 }
 
 __global__ void spell_next_kernel(const SpellArgs p) {
@@ -2605,9 +2686,25 @@ __global__ __launch_bounds__(64) void spell_merge_kernel(const SpellArgs p) {
   const bool scorer = p.status[i] == 0;
   if (scorer) {                                               // sort.SliceStable by ScoreNext desc — :127-131
     const uint32_t from = p.lm_from[i], to = p.lm_to[i];
-    for (uint32_t j = 0; j < n; j++) {
-      const uint32_t c = d_lm_count(p.values, from, to, cand[j], (int)lane);
-      if (lane == 0) cnt[j] = c;
+    // the continuation counts of all candidates together ([r4]: one wave-wide 64-ary search per candidate, one after the other,
+    // was 2 n dependent memory round trips per query): a list of at most 64 entries sits in the lanes and a candidate's count is
+    // a compare across the wave; a longer one is searched by every lane for ITS candidate
+    if (to - from <= 64u) {
+      const uint64_t v = from + lane < to ? p.values[from + lane] : ~0ull;
+      for (uint32_t j = 0; j < n; j++) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) == cand[j] && from + lane < to);
+        const uint32_t c = m ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, __builtin_ctzll(m)) : 0u;
+        if (lane == 0) cnt[j] = c;
+      }
+    } else {
+      for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t w = cand[j];
+        uint32_t lo = from, hi = to;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((uint32_t)(p.values[mid] >> 32) < w) lo = mid + 1u; else hi = mid; }
+        uint32_t c = 0;
+        if (lo < to) { const uint64_t v = p.values[lo]; if ((uint32_t)(v >> 32) == w) c = (uint32_t)v; }
+        cnt[j] = c;
+      }
     }
     __syncthreads();
     for (uint32_t j = lane; j < n; j += 64) {
