@@ -283,6 +283,13 @@ int sg_index_stats(const sg_index* index, sg_stats* out);
  * streamed — what bench.py's roofline.model_bytes is made of.  Synchronises the device. */
 int sg_index_launch_stats(sg_index* index, uint64_t out[4]);
 
+/* [r5] Queries the three-launch pipeline of ordinary fuzzy batches (plan -> stream -> verify) handed to the fused
+ * kernel, cumulative (wrapping at 2^32): out[0] the plan could not express them (more than 64 n-grams, a window of more than 63
+ * segments, a segment that needs docID-range passes, more groups / lists than a slot record holds), [1] their candidates
+ * overflowed the slots, [2] a matching document repeats a term (the secondary entries of SURVEY.md §A.3), [3] 0.
+ * Results never depend on which path answered.  Synchronises the device. */
+int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
+
 /* The forward index (doc -> distinct terms) of the primary replica, copied back for documents
  * first .. first+n-1: out_card[i] = cardinality, out_n[i] = number of distinct terms, out_keys[i*cap ..] their term keys. */
 int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, uint32_t* out_card, uint32_t* out_n,

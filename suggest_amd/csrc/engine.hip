@@ -184,6 +184,7 @@ struct BatchArgs {
   uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results, -, u64: 16-byte chunks of postings they streamed}: cumulative
   uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
+  uint32_t blk_base;      // [r5] sg_terms_kernel over a piece of the batch: workgroup b is slot blk_base + b
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -924,7 +925,10 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // kG8 = true: the index has dense terms with 8-bit gaps (13 postings per chunk; packed_store.inc) — their rows are decoded
 // and counted one at a time (count_row8).  Such an index is a long-list index: 2^12 counter words, 7 wavefronts per CU by
 // the LDS, so these instantiations may take the registers of two wavefronts per SIMD.
-template <bool kParts, bool kLM, bool kTight, bool kSlim, bool kG8>
+// kLoop = true [r5]: the launch behind the three-launch pipeline (pipeline.inc) — a few thousand persistent wavefronts that walk
+// the list of queries the pipeline left to this kernel (q_sel / q_sel_n), a stride of the grid apart; an empty list: they leave
+// at once.  Its own instantiation: the batch launches carry none of it.
+template <bool kParts, bool kLM, bool kTight, bool kSlim, bool kG8, bool kLoop = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3, kG8 ? 2 : 3))) void sg_search_kernel_t(const BatchArgs a) {
   using L = Lds<kSlim>;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -968,6 +972,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
   const bool splitting = a.split_ctl != nullptr;
   const bool primary = !kParts;
   uint32_t qi = blockIdx.x;
+  if (kLoop) {
+    if (qi >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) return;
+    if (lane == 0) tile_state[3] = qi;                    // (the position in the list lives in LDS across a query: no register for it)
+    qi = __builtin_amdgcn_readfirstlane(a.q_sel[qi]);
+  } else
   if (!kParts && a.q_sel) {
     // (both loads issued together — the list has an entry for every workgroup of the grid —: one memory round trip at the
     //  head of every query instead of two)
@@ -2035,6 +2044,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
   if (DBG_SKIP(8192u) && lane == 0 && k >= 6) { out_ids[k - 1] = (uint32_t)A; out_ids[k - 3] = qi; }
   PH(7)
   } while (0);
+  if (kLoop) {
+    __syncthreads();
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(tile_state[3]) + gridDim.x;
+    if (pos >= __builtin_amdgcn_readfirstlane(*a.q_sel_n)) break;
+    __syncthreads();
+    if (lane == 0) tile_state[3] = pos;
+    qi = __builtin_amdgcn_readfirstlane(a.q_sel[pos]);
+    __syncthreads();
+    continue;
+  }
   if (!kParts) break;
   }
   { const uint32_t qi = blockIdx.x; (void)qi; PH_FLUSH }
@@ -2054,7 +2073,7 @@ __global__ __launch_bounds__(64) void sg_terms_kernel(const BatchArgs a) {
   __shared__ uint64_t s_keys[SG_MAX_A];
   __shared__ uint32_t s_term[SG_MAX_A];
   const int lane = threadIdx.x;
-  uint32_t qi = blockIdx.x;
+  uint32_t qi = a.blk_base + blockIdx.x;
   if (a.q_sel) {                                             // a launch over a subset of the batch: the same subset
     const uint32_t sel_n = *a.q_sel_n, sel_q = a.q_sel[qi];
     if (qi >= __builtin_amdgcn_readfirstlane(sel_n)) return;
@@ -2813,7 +2832,10 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
   for (uint32_t i = threadIdx.x; i < n; i += 64) out_vals[i] = v[i];
 }
 
+#include "pipeline.inc"
+
 #define sg_search_kernel sg_search_kernel_t<false, false, false, false, false>
+#define sg_search_kernel_loop sg_search_kernel_t<false, false, false, false, false, true>
 #define sg_search_kernel_slim sg_search_kernel_t<false, false, false, true, false>
 #define sg_search_kernel_tight sg_search_kernel_t<false, false, true, false, false>
 #define sg_parts_kernel sg_search_kernel_t<true, false, false, false, false>

@@ -26,10 +26,10 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
         m = {k: int(v) for k, v in re.findall(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", b)}
         found[name] = m
     # the batch kernel without threshold tightening: full and slim LDS layout (template <kParts, kLM, kTight, kSlim, kG8>)
-    batch = [v for k, v in found.items() if re.search(r"sg_search_kernel_tILb0ELb0ELb0ELb[01]ELb0E", k)]
+    batch = [v for k, v in found.items() if re.search(r"sg_search_kernel_tILb0ELb0ELb0ELb[01]ELb0ELb0E", k)]
     assert len(batch) == 2, list(found)
     # ... and its instantiation for indexes with 8-bit-gap terms (the full layout; the registers of two wavefronts per SIMD)
-    g8 = [v for k, v in found.items() if "sg_search_kernel_tILb0ELb0ELb0ELb0ELb1E" in k]
+    g8 = [v for k, v in found.items() if "sg_search_kernel_tILb0ELb0ELb0ELb0ELb1ELb0E" in k]
     assert len(g8) == 1 and g8[0]["ScratchSize [bytes/lane]"] <= 64 and g8[0]["Occupancy [waves/SIMD]"] >= 2, g8
     for b in batch:
         assert b["ScratchSize [bytes/lane]"] <= 64, b      # a few spilled dwords in cold code are fine (hot blocks checked below)
@@ -39,7 +39,7 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
     # the stream loop keeps the next batch's four row loads in flight while it counts the current batch: the blocks
     # that issue the LDS counter atomics wait with vmcnt(4), never with vmcnt(0), and touch no scratch
     asm = open(tmp_path / "engine.s").read().split("\n")
-    for variant in ("_ZN2sg18sg_search_kernel_tILb0ELb0ELb0ELb0ELb0E", "_ZN2sg18sg_search_kernel_tILb0ELb0ELb0ELb1ELb0E"):
+    for variant in ("_ZN2sg18sg_search_kernel_tILb0ELb0ELb0ELb0ELb0ELb0E", "_ZN2sg18sg_search_kernel_tILb0ELb0ELb0ELb1ELb0ELb0E"):
         start = next(i for i, l in enumerate(asm) if l.startswith(variant))
         end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
         blocks, cur = [], []

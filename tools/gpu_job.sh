@@ -1,0 +1,55 @@
+#!/bin/bash
+# [r5] ONE driver for the round's GPU-box jobs (the r04*.sh one-offs of round 4 were one file per run):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_job.sh <job> [args...]'
+# Every job writes under gpurun_out/<tag>_*; what is worth keeping is copied to profiles/ by hand.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+job=$1; shift
+
+benchline() {  # config -> "config value frac"
+  python bench.py --config $1 --no-cpu-baseline --traffic none --steps ${2:-20} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['config'].get('baseline_config'), round(d['value']), 'ms', d['ms_per_step'])"
+}
+
+case $job in
+  pipe_ab)      # pipe_ab <tag> <config> <variants> [extra args]: fused vs pipeline variants on one resident index, rows compared
+    tag=$1; cfg=$2; var=$3; shift 3
+    timeout 1200 python tools/pipe_ab.py --config $cfg --variants "$var" "$@" 2>&1 | tee $O/${tag}_pipe_ab_${cfg}.txt | tail -40 ;;
+  pipe_prof)    # pipe_prof <tag> <config> <variant>: rocprofv3 kernel stats of the pipeline launches
+    tag=$1; cfg=$2; var=$3; shift 3
+    cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $O/${tag}_prof_${cfg} -o run -- python $R/tools/pipe_ab.py --config $cfg --variants "$var" --steps 10 "$@" > $O/${tag}_prof_${cfg}.log 2>&1
+    cd $R; db=$(find $O/${tag}_prof_${cfg} -name "*.db" | head -1); python tools/rocprof_summary.py $db "${tag} ${cfg} ${var}" 2>/dev/null | head -24 | cut -c1-130 | tee $O/${tag}_prof_${cfg}_summary.txt ;;
+  pmc)          # pmc <tag> <kernel substrings, |-separated> <config> <variant>: PMC counters of the matching kernels, separate passes (MI355X_MICROARCH.md)
+    tag=$1; pat=$2; cfg=$3; var=$4; shift 4
+    OUT=$O/${tag}_pmc_${cfg}; mkdir -p $OUT; cd /tmp; i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+               "SQ_INSTS_LDS SQ_INSTS_LDS_ATOMIC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU" \
+               "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "GRBM_GUI_ACTIVE TA_BUSY_avr" \
+               "SQ_INSTS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pass$i -- python $R/tools/pipe_ab.py --config $cfg --variants "$var" --steps 3 "$@" > $OUT/pass$i.log 2>&1
+    done
+    cd $R; python - "$OUT" "$pat" <<'PY' | tee $O/${tag}_pmc_${cfg}.txt
+import csv, glob, collections, sys
+out, pats = sys.argv[1], sys.argv[2].split("|")
+acc = collections.defaultdict(list)
+for p in sorted(glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(p)):
+        name = r.get("Kernel_Name", "")
+        for pt in pats:
+            if pt in name:
+                acc[(pt, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (pt, k), v in sorted(acc.items()):
+    v = v[len(v) // 2:]          # the later half of the dispatches: steady state
+    print("%-22s %-24s per-dispatch avg %.6g (n=%d)" % (pt, k, sum(v) / len(v), len(v)))
+PY
+    ;;
+  suite)        # suite <tag> [pytest args]: the GPU suite
+    tag=$1; shift
+    timeout 2400 python -m pytest tests -m gpu -x -q "$@" > $O/${tag}_pytest.log 2>&1; tail -5 $O/${tag}_pytest.log ;;
+  bench)        # bench <tag> [bench args]: the default bench line
+    tag=$1; shift
+    timeout 1500 python bench.py "$@" > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -3 $O/${tag}_bench.err; tail -c 3000 $O/${tag}_bench.json ;;
+  sh)           # sh <command...>: anything else
+    bash -c "$*" ;;
+  *) echo "unknown job $job"; exit 2 ;;
+esac
