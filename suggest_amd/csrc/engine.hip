@@ -184,7 +184,6 @@ struct BatchArgs {
   uint32_t* pre_terms;    // [n_q][SG_MAX_A] its term ids
   uint32_t* fill_stat;    // {sampled fuzzy queries whose top-k ended full, sampled fuzzy queries, their results, -, u64: 16-byte chunks of postings they streamed}: cumulative
   uint32_t fill_mask;     // ... sampled: queries with (index & fill_mask) == 0 — one in 32 of a large batch, every one of a small
-  uint32_t blk_base;      // [r5] sg_terms_kernel over a piece of the batch: workgroup b is slot blk_base + b
   unsigned long long* prof;  // phase cycle counters (only read by SG_PHASE_TIMING builds)
   uint32_t dbg_skip;         // ablation bits (SG_PHASE_TIMING builds only; results are wrong when set)
 };
@@ -2073,7 +2072,7 @@ __global__ __launch_bounds__(64) void sg_terms_kernel(const BatchArgs a) {
   __shared__ uint64_t s_keys[SG_MAX_A];
   __shared__ uint32_t s_term[SG_MAX_A];
   const int lane = threadIdx.x;
-  uint32_t qi = a.blk_base + blockIdx.x;
+  uint32_t qi = blockIdx.x;
   if (a.q_sel) {                                             // a launch over a subset of the batch: the same subset
     const uint32_t sel_n = *a.q_sel_n, sel_q = a.q_sel[qi];
     if (qi >= __builtin_amdgcn_readfirstlane(sel_n)) return;

@@ -33,7 +33,7 @@ d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to
 d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-NAMES = dict(nw="SG_PIPE_NW", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
+NAMES = dict(nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
              level="SG_FILTER_LEVEL", floor="SG_T_FLOOR")
 
 
