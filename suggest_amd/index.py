@@ -374,7 +374,10 @@ class NGramIndex:
         assert ids.size >= n_q * k and scores.size >= n_q * k and counts.size >= n_q
         t = C.c_void_p()
         with self._use() as h:
-            _lib.check(_lib.lib().sg_suggest_submit_on(h, int(replica), blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, resolve(metric).code,
+            code = resolve(metric).code
+            if code is None:
+                raise ValueError("suggest_submit takes the metrics with a device twin (jaccard, cosine, dice, exact, overlap); tabulate others with metric_tables + suggest_batch")
+            _lib.check(_lib.lib().sg_suggest_submit_on(h, int(replica), blob.ctypes.data if blob.size else None, offs.ctypes.data, n_q, code,
                                                        float(similarity), int(k), ids.ctypes.data, scores.ctypes.data, counts.ctypes.data, C.byref(t)))
         return Ticket(t, (blob, offs, ids, scores, counts))
 

@@ -96,11 +96,27 @@ def OverlapMetric():
     return _Overlap()
 
 
+class _Duck:
+    """an object with the four methods of metric.Metric that cannot carry a `code` attribute itself"""
+    code = None
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.MinY, self.MaxY, self.Threshold, self.Distance = inner.MinY, inner.MaxY, inner.Threshold, inner.Distance
+
+
 BY_NAME = {"jaccard": JaccardMetric, "cosine": CosineMetric, "dice": DiceMetric, "exact": ExactMetric, "overlap": OverlapMetric}
 
 
 def resolve(m):
     if isinstance(m, Metric) or all(hasattr(m, f) for f in ("MinY", "MaxY", "Threshold", "Distance")):
+        if not hasattr(m, "code"):
+            # a caller's own implementation of the interface: no device twin — it is tabulated (NGramIndex.metric_tables).  Normalised
+            # here so that every caller can read m.code (an object that cannot take attributes is wrapped)
+            try:
+                m.code = None
+            except AttributeError:
+                m = _Duck(m)
         return m
     if isinstance(m, str):
         # metric names of the HTTP handler, internal/suggest/api/suggest_handler.go:26-34

@@ -1,0 +1,127 @@
+"""[r5] The three-launch pipeline of ordinary fuzzy batches (plan -> stream -> verify, suggest_amd/csrc/pipeline.inc) against the
+CPU oracle: bit-exact ids, order and scores through the C ABI, whatever its knobs, and whichever queries it hands back to the
+fused kernel (pkg/suggest/suggester.go:46-131, pkg/merger/cp_merge.go:19-120 are what both must reproduce)."""
+import numpy as np
+import pytest
+
+import oracle
+from test_gpu_parity import METRICS, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n_docs, n_q, desc=None, seed=1, **variant):
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    d = dict(synth.DESCRIPTION, **(desc or {}))
+    blob, offs = synth.make_dict(n_docs, seed=seed, **variant)
+    qb, qo = synth.make_queries(n_q, blob, offs, seed=seed + 1)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**d))
+    ora = oracle.OracleIndex(blob=blob, offs=offs, **d)
+    return gpu, ora, qb, qo
+
+
+@pytest.fixture(scope="module")
+def synth_pipe():
+    gpu, ora, qb, qo = _pair(60000, 4096)
+    gpu.tune(SG_PIPE=1)                       # every eligible launch (the default takes it only where the index's queries stream enough)
+    return gpu, ora, qb, qo
+
+
+def _delta(gpu, fn):
+    s0 = gpu.pipe_stats()
+    out = fn()
+    s1 = gpu.pipe_stats()
+    return out, {k: s1[k] - s0[k] for k in s1}
+
+
+@pytest.mark.parametrize("metric,alpha", METRICS)
+@pytest.mark.parametrize("k", [1, 10, 64])
+def test_pipeline_parity(synth_pipe, metric, alpha, k):
+    gpu, ora, qb, qo = synth_pipe
+    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
+
+
+@pytest.mark.parametrize("knobs", [dict(SG_PIPE_SUB=3), dict(SG_PIPE_SUB=5), dict(SG_PIPE_NW=4), dict(SG_PIPE_NW=4, SG_PIPE_SUB=3),
+                                   dict(SG_PIPE_LOG2_CNT=9), dict(SG_PIPE_LOG2_CNT=11, SG_T_FLOOR=4), dict(SG_FILTER_LEVEL=7, SG_T_FLOOR=2),
+                                   dict(SG_FILTER_LEVEL=0), dict(SG_ORDER=0)])
+def test_rows_do_not_depend_on_the_pipeline_knobs(synth_pipe, knobs):
+    gpu, ora, qb, qo = synth_pipe
+    base = dict(SG_PIPE_SUB=4, SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_T_FLOOR=8, SG_FILTER_LEVEL=4, SG_ORDER=1)
+    try:
+        gpu.tune(**knobs)
+        for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20), ("dice", 0.7, 5)):
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
+    finally:
+        gpu.tune(**base)
+
+
+def test_candidate_overflow_goes_to_the_fused_kernel(synth_pipe):
+    """two candidate slots per query: nearly every query with a match overflows them and is answered by the fused kernel
+    behind the three launches — the rows must not tell"""
+    gpu, ora, qb, qo = synth_pipe
+    try:
+        gpu.tune(SG_PIPE_CAND_CAP=2)
+        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10))
+    finally:
+        gpu.tune(SG_PIPE_CAND_CAP=64)
+    assert_same(res, ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
+    assert d["overflow"] > 100, d
+
+
+def test_plan_hands_back_what_it_cannot_express(synth_pipe):
+    """the smallest counter array: single segments that need docID-range passes are the fused kernel's"""
+    gpu, ora, qb, qo = synth_pipe
+    try:
+        gpu.tune(SG_PIPE_LOG2_CNT=9, SG_FILTER_LEVEL=0)
+        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.3, k=10))
+    finally:
+        gpu.tune(SG_PIPE_LOG2_CNT=13, SG_FILTER_LEVEL=4)
+    assert_same(res, ora.suggest_batch(qb, qo, "cosine", 0.3, 10))
+    assert d["unplanned"] > 0, d
+
+
+def test_documents_that_repeat_a_term_and_near_duplicates():
+    """an alphabet without the digits: they normalise to the pad, documents repeat terms (secondary entries — the
+    fused kernel's per-list view), and families of near-duplicates flag dozens of postings per query"""
+    gpu, ora, qb, qo = _pair(40000, 4096, desc=dict(alphabet=("english", "$")), seed=11, families=3)
+    gpu.tune(SG_PIPE=1)
+    for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 5), ("dice", 0.6, 64)):
+        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k))
+        assert_same(res, ora.suggest_batch(qb, qo, metric, alpha, k))
+    assert d["repeats"] + d["overflow"] > 0, d
+
+
+def test_long_and_odd_queries_in_a_pipeline_batch(synth_pipe):
+    """queries of every kind in one batch: empty, shorter than an n-gram, above 64 n-grams (the plan hands them back), above 128
+    (sg_long_kernel), non-ASCII, spaces only"""
+    from suggest_amd import pack_strings
+    gpu, ora, qb, qo = synth_pipe
+    base = [qb[int(qo[i]):int(qo[i + 1])].tobytes() for i in range(3000)]
+    odd = [b"", b"a", b"  ", b"ab", "été naïve".encode(), b"x" * 70, b"abcdefghij" * 9, b"q" * 140, b"the quick brown fox " * 8,
+           bytes(range(1, 60)), b"A1B2C3D4E5F6", b"\xff\xfe\xfd abc"]
+    qs = []
+    for i, q in enumerate(base):
+        qs.append(q)
+        if i % 250 == 0:
+            qs.extend(odd)
+    b2, o2 = pack_strings(qs)
+    for metric, alpha in (("jaccard", 0.5), ("cosine", 0.3)):
+        assert_same(gpu.suggest_batch(blob=b2, offs=o2, metric=metric, similarity=alpha, k=10), ora.suggest_batch(b2, o2, metric, alpha, 10))
+
+
+def test_pipeline_with_a_tabulated_metric(synth_pipe):
+    """an opaque metric.Metric as host-built tables (pkg/metric/metric.go:7-16) goes through the same three launches"""
+    gpu, ora, qb, qo = synth_pipe
+    tabs = gpu.metric_tables("jaccard", 0.6, 80)
+    try:
+        assert_same(gpu.suggest_batch(blob=qb, offs=qo, k=10, tables=tabs), ora.suggest_batch(qb, qo, "jaccard", 0.6, 10))
+    finally:
+        tabs.close()
+
+
+def test_default_policy_takes_the_pipeline_where_the_queries_are_heavy_enough():
+    """the default (SG_PIPE=2): an index whose queries stream few postings keeps the fused kernel; nothing else changes"""
+    gpu, ora, qb, qo = _pair(30000, 4096, seed=21)
+    res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10))
+    assert_same(res, ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
+    assert d == {"unplanned": 0, "overflow": 0, "repeats": 0}, d

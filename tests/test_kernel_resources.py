@@ -36,6 +36,50 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
         assert b["Occupancy [waves/SIMD]"] >= 3, b
         assert b["VGPRs"] <= 168, b
 
+    # [r5] the pipeline's launches (pipeline.inc).  The stream kernel: 64 registers and 80 scalar registers at most — eight
+    # wavefronts per SIMD = four workgroups of eight per CU (at 82 .. 96 scalar registers the hardware admits seven, whatever the
+    # compiler reports: three workgroups) — and nothing in scratch.
+    res = {}
+    for b in blocks[1:]:
+        nm = b.split()[0]
+        res[nm] = {k: int(v) for k, v in re.findall(r"remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", b)}
+    stream = [v for k, v in res.items() if "sg_stream_kernelILi" in k]
+    assert len(stream) == 2, list(res)
+    for b in stream:
+        assert b["VGPRs"] <= 64 and b["TotalSGPRs"] <= 80 and b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8, b
+    plan = [v for k, v in res.items() if "sg_plan_kernel" in k]
+    assert len(plan) == 1 and plan[0]["ScratchSize [bytes/lane]"] == 0 and plan[0]["Occupancy [waves/SIMD]"] >= 6, plan   # (its 6 KB of LDS allow 26 wavefronts per CU)
+    # ... and its row loop: a row's seven counter atomics sit in blocks that wait for the row with vmcnt(1) (the next row's load
+    # stays in flight), and the wait that ends the loop — vmcnt(0), before the last groups' barriers clear counters out of
+    # registers the compiler takes for free — names the row registers
+    asm_all = open(tmp_path / "engine.s").read().split("\n")
+    for variant in ("_ZN2sg16sg_stream_kernelILi8E", "_ZN2sg16sg_stream_kernelILi4E"):
+        start = next(i for i, l in enumerate(asm_all) if l.startswith(variant))
+        end = next(i for i in range(start, len(asm_all)) if asm_all[i].startswith(".Lfunc_end"))
+        body = [l.strip() for l in asm_all[start:end]]
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx4")]
+        assert len(loads) == 3, loads                                   # first row, and the two of the ping-pong
+        assert sum(l == "s_waitcnt vmcnt(1)" for l in body) == 2
+        last_w0 = max(i for i, l in enumerate(body) if l == "s_waitcnt vmcnt(0)")
+        assert last_w0 > loads[-1]
+        # no compiler-made copy OUT of a row register anywhere between the first row load and that wait (the signature of a value
+        # moved while its load is in flight; the decode reads the registers with and / sdwa adds / shifts, never with v_mov)
+        regs = set()
+        for i in loads:
+            m = re.search(r"v\[(\d+):(\d+)\]", body[i])
+            regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for l in body[loads[0]:last_w0]:
+            if l.startswith("v_mov") and "dpp" not in l:
+                dst, src = l.split(None, 1)[1].split(",", 1)
+
+                def named(t):
+                    out = {int(x) for x in re.findall(r"\bv(\d+)\b", t)}
+                    for a_, b_ in re.findall(r"v\[(\d+):(\d+)\]", t):
+                        out |= set(range(int(a_), int(b_) + 1))
+                    return out
+                # (a row register set from another: the zero-initialisation of a buffer no load has been issued into)
+                assert not (named(src) & regs) or (named(dst) <= regs), l
+
     # the stream loop keeps the next batch's four row loads in flight while it counts the current batch: the blocks
     # that issue the LDS counter atomics wait with vmcnt(4), never with vmcnt(0), and touch no scratch
     asm = open(tmp_path / "engine.s").read().split("\n")
