@@ -21,10 +21,15 @@ N > 1 (weak scaling: every GPU holds a full index replica and gets its own batch
                           PCIe-inclusive by construction, so its line says so (`config.pcie_inclusive`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline      achieved / frac = MEASURED HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x 1024 x 2, the gfx950
-                correction of MI355X_MICROARCH.md; live child pass of the same workload, else the committed figure in
-                profiles/traffic.json) / the search kernel's average launch duration (HIP events on the launch stream)
-                / the 8 TB/s peak — a physical fraction, always <= 1.
+  roofline      achieved / frac = MEASURED memory traffic per call (rocprofv3 --pmc FETCH_SIZE x 1024 x 2 = the 128-byte lines
+                fetched past the L2, calibrated on this box: profiles/r05_membench.txt; live child pass of the same workload,
+                else the committed figure in profiles/traffic.json) / the call's average duration (HIP events on the launch
+                stream) / the 8 TB/s peak — a physical fraction, always <= 1.  No counter separates Infinity-Cache hits from
+                HBM reads (membench: TCC_EA0_RDREQ_DRAM = TCC_EA0_RDREQ inside the cache as outside), so it is an UPPER
+                bound of the HBM fraction; frac_of_achievable = against the line traffic the memory system delivers for random
+                contiguous segments on this box (7.2 TB/s, profiles/membench.json).  [r5] `kernels` = per-kernel time and
+                traffic of the call (plan / stream / verify of the pipeline, or the fused kernel), `dominant` the stream
+                (or fused) kernel's own fraction.
                 effective_gbps / effective_frac = ALGORITHMIC bytes per launch (every posting of every
                 query term in every admissible segment once, sg_suggest_algorithmic_bytes) over the same duration: the
                 rate a full ScanCount scan would need to answer as fast.  List skipping and compressed postings read
@@ -229,6 +234,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         gather(i % n_b)
     env.barrier()
     ls0 = index.launch_stats()
+    ps0 = index.pipe_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t_start = time.perf_counter()
     for i in range(steps):
@@ -240,6 +246,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     ls1 = index.launch_stats()
+    ps1 = index.pipe_stats()
+    pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1}    # queries per call the pipeline left to the fused kernel
     d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)
     # bytes the PACKED algorithm has to move per launch: 16 B x the chunks of the lists the kernel streams (the k longest are
     # skipped, 7 postings per chunk), from the kernel's own count over its sampled queries (one in 32), + queries in + rows out
@@ -397,12 +405,12 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         del ora
 
     key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (w["dict_size"], n_q, w["ngram"], w["metric"], w["similarity"], k, w["variant"])
-    traffic, traffic_src = args.traffic_bytes if w["name"] == args.config else None, None
+    traffic, traffic_src, per_kernel = args.traffic_bytes if w["name"] == args.config else None, None, None
     if traffic:
         traffic_src = "--traffic-bytes"
     under_profiler = any(kk.startswith(("ROCPROF", "ROCP_")) for kk in os.environ)     # (no profiler inside a profiler)
     if traffic is None and traffic_mode in ("auto", "live") and rank == 0 and world == 1 and not (under_profiler and traffic_mode == "auto"):
-        traffic, traffic_src = _live_traffic(args, w, log)
+        traffic, traffic_src, per_kernel = _live_traffic(args, w, log)
         if traffic is None and traffic_mode == "live":
             raise SystemExit("live PMC pass failed: " + str(traffic_src))
         if traffic is None:
@@ -427,22 +435,41 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     avg_ms = float(np.mean(kernel_ms))
     effective = alg_timed / (avg_ms * 1e-3) / 1e9
     wire = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+    try:
+        mb = json.load(open(os.path.join(ROOT, "profiles", "membench.json")))
+        achievable = float([x for x in mb["segments"] if x["seg_bytes"] == 1024][0]["lines_GBps_1GiB"])
+    except (OSError, ValueError, KeyError, IndexError):
+        achievable = 6290.0              # (the guide's copy ceiling)
+    dominant = None
+    if per_kernel:
+        dk = per_kernel.pop("_dominant")
+        d = per_kernel[dk]
+        if d["ms_per_call_under_profiler"] > 0:
+            d_gbps = d["traffic_bytes_per_call"] / (d["ms_per_call_under_profiler"] * 1e-3) / 1e9
+            dominant = {"kernel": {"stream": "sg_stream_kernel", "fused": "sg_search_kernel_t"}[dk], "ms": d["ms_per_call_under_profiler"],
+                        "traffic": d["traffic_bytes_per_call"], "achieved": d_gbps, "frac": d_gbps / HBM_PEAK_GBS, "frac_of_achievable": d_gbps / achievable,
+                        "share_of_call_time": d["ms_per_call_under_profiler"] / max(1e-9, sum(v["ms_per_call_under_profiler"] for v in per_kernel.values()))}
+    pipe_on = bool(per_kernel and "stream" in per_kernel) if per_kernel else None
     roof = {"bound": "hbm", "achieved": wire, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wire / HBM_PEAK_GBS if wire else None,
             "traffic": traffic, "traffic_source": traffic_src,
+            "achievable": achievable, "frac_of_achievable": wire / achievable if wire else None,
+            "dominant": dominant, "kernels": per_kernel,
             "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBS,
             "traffic_over_algorithmic": traffic / alg_timed if traffic else None,
             "model_bytes": model_bytes, "traffic_over_model": traffic / model_bytes if traffic and model_bytes else None,
-            "kernel": "sg_search_kernel_t", "kernel_ms_avg": avg_ms,
+            "kernel": ("sg_plan_kernel + sg_stream_kernel + sg_verify_kernel (pipeline.inc)" if pipe_on else "sg_search_kernel_t"), "kernel_ms_avg": avg_ms,
             "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
             "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
-            "note": "achieved/frac = measured HBM bytes per launch (PMC) / kernel time: the physical fraction of the 8 TB/s peak. "
-                    "effective_* = algorithmic (ScanCount-volume, SURVEY.md 8d) bytes / the same time: list skipping and the compressed "
-                    "posting store read less than that volume, so it may exceed the peak and is not a bandwidth. "
-                    "model_bytes = what the packed algorithm must move: 16 B x the chunks of the streamed lists (counted by the kernel over "
-                    "its sampled queries) + queries in + 12 B x k rows out; traffic / model_bytes = what is read on top of that "
-                    "(forward-index records of verified candidates, seg_off rows, term table, dead lanes' lines). "
-                    "kernel time = HIP events around one sg_suggest_batch_device call: the search launch, the parts launch of split "
-                    "queries, the tokeniser launch (sg_terms_kernel) and the two query-ordering launches (~10 us) before it"}
+            "note": "achieved/frac = measured memory traffic per call (PMC: 128-byte lines fetched past the L2, every kernel of the call) / the call's time "
+                    "(HIP events around one sg_suggest_batch_device call, no profiler): the physical fraction of the 8 TB/s HBM peak — an upper bound of the "
+                    "HBM fraction, no counter separates Infinity-Cache hits from HBM reads (profiles/membench.json).  achievable = the line traffic the memory "
+                    "system delivers on this box for random contiguous 1 KiB segments over 1 GiB (tools/membench.hip).  dominant = the stream (or fused) "
+                    "kernel alone, time and traffic from the profiler pass.  effective_* = algorithmic (ScanCount-volume, SURVEY.md 8d) bytes / the call's time: "
+                    "list skipping and the packed posting store read less than that volume, so it may exceed the peak and is not a bandwidth — superseded "
+                    "by model_bytes as the numerator that describes this engine (BASELINE.md).  model_bytes = what the packed algorithm must move: 16 B x the "
+                    "chunks of the streamed lists (counted by the plan / the fused kernel over its sampled queries) + queries in + 12 B x k rows out; "
+                    "traffic / model_bytes = what is read on top of that (lines a list only partly fills, slot records, forward-index records of verified "
+                    "candidates, seg_off rows, term table)"}
     rec = {
         "value": total_q / elapsed,
         "unit": "queries/s",
@@ -461,7 +488,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "per_rank": per_rank,
                    "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
                              "build": args.build},
-                   "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt]))},
+                   "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt])),
+                   "pipeline": {"on": pipe_on, "left_to_fused_kernel_per_call": pipe_fb}},
         "roofline": roof,
         "cpu_baseline": cpu,
     }
@@ -693,11 +721,24 @@ def main_replicas(env, args, w):
     print(json.dumps(out), flush=True)
 
 
+SEARCH_KERNELS = (("stream", "sg_stream_kernel"), ("plan", "sg_plan_kernel"), ("verify", "sg_verify_kernel"), ("fused", "sg_search_kernel_t<false, false,"),
+                  ("parts", "sg_search_kernel_t<true, false,"), ("tokenise", "sg_terms_kernel"), ("order", "query_order_"), ("long", "sg_long_kernel"))
+
+
+def _kernel_kind(name):
+    for kind, pat in SEARCH_KERNELS:
+        if pat in name:
+            return kind
+    return None
+
+
 def _live_traffic(args, w, log):
-    """HBM bytes per launch of the search kernel, measured now: this script again, as a child under `rocprofv3 --pmc
+    """Memory traffic per call of sg_suggest_batch_device, measured now: this script again, as a child under `rocprofv3 --pmc
     FETCH_SIZE --kernel-trace` (PMC counters cannot be read from inside a process), a few steps of the same workload.
-    bytes = FETCH_SIZE [KB] x 1024 x 2 — the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM section).
-    -> (bytes, source) or (None, reason)."""
+    bytes = FETCH_SIZE [KB] x 1024 x 2 = 128-byte lines fetched past the L2 (profiles/r05_membench.txt: equal to TCC_EA0_RDREQ x 128
+    for random segments of 256 B ... 4 KiB).  Every kernel of the call is counted (plan / stream / verify of the pipeline, the fused
+    kernel and what it leaves to the parts launch, tokeniser, ordering), each with its average duration.
+    -> (bytes, source, per_kernel) or (None, reason, None)."""
     import csv
     import glob
     import shutil
@@ -705,7 +746,7 @@ def _live_traffic(args, w, log):
     import tempfile
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not rocprof:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
     steps, warm = (4, 2) if w["name"] not in ("cfg4", "skewed") else (2, 1)
     cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
@@ -717,24 +758,34 @@ def _live_traffic(args, w, log):
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
         if r.returncode != 0:
-            return None, "rocprofv3 child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:])
-        main_k, parts_k = [], []
+            return None, "rocprofv3 child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:]), None
+        kb, ns, n = {}, {}, {}
         for path in sorted(glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)):
             for row in csv.DictReader(open(path)):
-                if row.get("Counter_Name") != "FETCH_SIZE":
-                    continue
-                if "sg_search_kernel_t<false, false," in row["Kernel_Name"]:
-                    main_k.append(float(row["Counter_Value"]))
-                elif "sg_search_kernel_t<true, false," in row["Kernel_Name"] or "sg_terms_kernel" in row["Kernel_Name"]:
-                    parts_k.append(float(row["Counter_Value"]))      # (the other launches of a call: split queries' parts, the tokeniser)
-        if not main_k:
-            return None, "no FETCH_SIZE rows for the search kernel in the child's counter CSV"
-        kb = sum(main_k) / len(main_k) + (sum(parts_k) / len(main_k) if parts_k else 0.0)
-        log("[%s] live PMC pass: FETCH_SIZE %.6g KB per launch over %d launches (%.0fs)" % (w["name"], kb, len(main_k), time.time() - t0))
-        return kb * 1024 * 2, ("live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass of this run, %d launches of this workload "
-                               "(search + parts + tokeniser kernels): FETCH_SIZE %.6g KB x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (len(main_k), kb))
+                kind = _kernel_kind(row.get("Kernel_Name", ""))
+                if kind and row.get("Counter_Name") == "FETCH_SIZE":
+                    kb[kind] = kb.get(kind, 0.0) + float(row["Counter_Value"])
+                    n[kind] = n.get(kind, 0) + 1
+        for path in sorted(glob.glob(tmp + "/**/*kernel_trace.csv", recursive=True)):
+            for row in csv.DictReader(open(path)):
+                kind = _kernel_kind(row.get("Kernel_Name", ""))
+                if kind:
+                    ns[kind] = ns.get(kind, 0.0) + float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        main = "stream" if n.get("stream") else "fused"
+        calls = n.get(main, 0)
+        if not calls:
+            return None, "no FETCH_SIZE rows for the search kernels in the child's counter CSV", None
+        total_kb = sum(kb.values()) / calls
+        per = {kind: {"launches_per_call": n[kind] / calls, "traffic_bytes_per_call": kb[kind] / calls * 2048.0,
+                      "ms_per_call_under_profiler": ns.get(kind, 0.0) / calls * 1e-6} for kind in n}
+        per["_dominant"] = main
+        log("[%s] live PMC pass: FETCH_SIZE %.6g KB per call over %d calls (%.0fs); %s" %
+            (w["name"], total_kb, calls, time.time() - t0, ", ".join("%s %.3f ms" % (k_, v["ms_per_call_under_profiler"]) for k_, v in per.items() if k_[0] != "_")))
+        return total_kb * 2048.0, ("live: rocprofv3 --pmc FETCH_SIZE --kernel-trace child pass of this run, %d calls of this workload, every kernel of the call "
+                                   "(%s): FETCH_SIZE %.6g KB x 1024 x 2 (128-byte lines past the L2; profiles/r05_membench.txt)" %
+                                   (calls, " + ".join(k_ for k_ in per if k_[0] != "_"), total_kb)), per
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
-        return None, "live PMC pass failed: %r" % (exc,)
+        return None, "live PMC pass failed: %r" % (exc,), None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -43,6 +43,32 @@ for (pt, k), v in sorted(acc.items()):
     print("%-22s %-24s per-dispatch avg %.6g (n=%d)" % (pt, k, sum(v) / len(v), len(v)))
 PY
     ;;
+  membench)     # membench <tag>: the memory system on this engine's access pattern, timed and under the PMC counters (roofline calibration)
+    tag=$1; shift
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/membench tools/membench.hip || exit 1
+    {
+      echo "# tools/membench.hip: random contiguous segments, 2 GiB per launch, every load instruction fully useful; timed without the profiler"
+      for buf in 128 1024 8192; do for seg in 128 256 512 1024 2048 4096 16384; do for inf in 1 2 4; do /tmp/membench $buf $seg $inf 5; done; done; done
+      echo "# under rocprofv3 --pmc (per-dispatch average over the 6 launches of a run): counter value, and bytes_per_launch / value"
+      cd /tmp
+      for buf in 128 1024; do for seg in 256 1024 4096; do
+        for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
+          rm -rf /tmp/mb_pmc; rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/mb_pmc -- /tmp/membench $buf $seg 4 5 > /tmp/mb.log 2>&1
+          python - $buf $seg <<'PY'
+import csv, glob, collections, sys
+acc = collections.defaultdict(list)
+for p in glob.glob("/tmp/mb_pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        if "gather" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+b = float(2**31)
+for k, v in sorted(acc.items()):
+    m = sum(v) / len(v)
+    print("buf_MiB %5s seg_B %5s %-28s %.6g  bytes/value %.3f" % (sys.argv[1], sys.argv[2], k, m, b / m if m else 0))
+PY
+        done
+      done; done
+    } 2>&1 | tee $O/${tag}_membench.txt ;;
   suite)        # suite <tag> [pytest args]: the GPU suite
     tag=$1; shift
     timeout 2400 python -m pytest tests -m gpu -x -q "$@" > $O/${tag}_pytest.log 2>&1; tail -5 $O/${tag}_pytest.log ;;
