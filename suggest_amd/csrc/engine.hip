@@ -2761,7 +2761,7 @@ __device__ __forceinline__ uint32_t d_order_bin(const uint64_t* q_offs, const ui
 // atomics (the sums would grow with the square of the blocks).
 #define SG_ORDER_DIRECT_BLOCKS 128u
 __global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* ctl,
-                                                                  const uint8_t* flag, uint32_t* blk_hist) {
+                                                                  const uint8_t* flag, uint32_t* blk_hist, uint32_t* zero0, uint32_t* zero1) {
   __shared__ uint32_t hist[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024u + tid;
   if (tid < 256u) hist[tid] = 0u;
@@ -2770,7 +2770,13 @@ __global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t*
   __syncthreads();
   if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
   if (blk_hist && tid < 256u) blk_hist[blockIdx.x * 256u + tid] = hist[tid];
-  if (i == 0u) ctl[0] = n_q;
+  if (i == 0u) {
+    ctl[0] = n_q;
+    // [r5] the call's other control words (the list of queries for sg_long_kernel, the pipeline's list for the fused kernel): zeroed
+    // here, ahead of the launches that append to them, instead of by a memset launch each
+    if (zero0) *zero0 = 0u;
+    if (zero1) *zero1 = 0u;
+  }
 }
 __global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_t* q_offs, const uint32_t* q_len, uint32_t n_q, int shortest_first, uint32_t* order, uint32_t* ctl,
                                                                     const uint8_t* flag, const uint32_t* blk_hist) {
