@@ -396,10 +396,23 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         n_1 = int(max(16, min(n_s, cpu["value"] / max(used, 1) * budget / 2)))      # ~budget/2 s on one thread
         (_, _, _, used1), dt1 = timed(n_1, 1)
         cpu["one_thread"] = {"value": n_1 / dt1, "unit": "queries/s", "cores": used1, "sample": "first %d queries of batch 0" % n_1}
+        if quota and int(round(quota)) < used:            # as many threads as the container's CPU quota grants cores: not oversubscribed
+            tq = max(1, int(round(quota)))
+            n_q_ = int(max(16, min(n_s, cpu["value"] * budget / 2)))
+            (_, _, _, usedq), dtq = timed(n_q_, tq)
+            cpu["at_quota"] = {"value": n_q_ / dtq, "unit": "queries/s", "cores": usedq, "sample": "first %d queries of batch 0" % n_q_,
+                               "note": "threads = the cgroup CPU quota (the all-threads leg above oversubscribes it)"}
         valid = np.arange(k)[None, :] < np.minimum(oc, k)[:, None]
         same = np.array_equal(cnt[0][:n_s], oc) and np.array_equal(ids[0][:n_s][valid], oi[valid]) and \
             np.array_equal(sc[0][:n_s].view(np.uint64)[valid], os_.view(np.uint64)[valid])
         parity = {"checked_queries": int(n_s), "bit_exact": bool(same)}
+        # the Go reference's threshold tightening can resolve an exact tie at the k-th place differently from run to
+        # run; parity is defined against the untightened order.  How many of the checked queries are tie-sensitive (k-th and
+        # (k+1)-th best scores bit-equal) says how many rows that caveat can touch at all: the oracle at k + 1 on a subsample.
+        n_t = int(min(n_s, 4096))
+        (_, ts_, tc_, _), _ = (ora.suggest_batch(qb[:int(qo[n_t])], qo[:n_t + 1], w["metric"], w["similarity"], k + 1, threads=cores), None)
+        tie = int(np.sum((tc_ > k) & (ts_.view(np.uint64)[:, k - 1] == ts_.view(np.uint64)[:, k])))
+        parity["tie_sensitive_queries"] = {"count": tie, "of": n_t, "note": "k-th and (k+1)-th best scores bit-equal (SURVEY.md A.6)"}
         log("[%s] cpu baseline %.0f q/s on %d threads, %.0f q/s on one; GPU result bit-exact vs oracle on the sample: %s"
             % (w["name"], cpu["value"], used, cpu["one_thread"]["value"], same))
         del ora

@@ -106,7 +106,7 @@ func (b *Builder) Build() (suggest.NGramIndex, error) {
 		}
 	}
 	e := &engine{h: h, reqs: make(chan *request, 4096), closing: make(chan struct{}), done: make(chan struct{}), multi: len(b.Devices) > 1,
-		tables: map[tablesKey]*C.sg_metric_tables{}}
+		tables: map[tablesKey]*tableEntry{}}
 	var st C.sg_stats
 	C.sg_index_stats(h, &st)
 	e.segments = int(st.n_segments)
@@ -140,8 +140,23 @@ type engine struct {
 	segments int
 	lastK    int32 // atomic: the k the last fuzzy factory turned out to have (probed first next time)
 	tmu      sync.Mutex
-	tables   map[tablesKey]*C.sg_metric_tables
+	tables   map[tablesKey]*tableEntry // at most maxTableSets, least recently used out first; nil once the index is closed
+	tclock   uint64
 }
+
+// A cached table set and when it was last asked for.  The cache holds ONE reference of the set (sg_metric_tables_retain /
+// _release count them); every call that uses it holds its own, so a set evicted or dropped by Close while a call is in flight
+// stays in HBM until that call returns.
+type tableEntry struct {
+	t    *C.sg_metric_tables
+	used uint64
+}
+
+const (
+	maxTableSets  = 8   // table sets kept per index: (metric value, similarity, aMax) triples a service really alternates between
+	maxTableTerms = 256 // longest query (n-grams) a table set is built for: (aMax + 1)^2 x segments doubles — 34 MB at 64 segments;
+	// a longer query comes back SG_COUNT_TOO_LONG from the engine instead of costing gigabytes of tables
+)
 
 var errClosed = errors.New("suggesthip: index is closed")
 
@@ -254,8 +269,8 @@ func (e *engine) dispatch() {
 			}
 		}
 		e.tmu.Lock()
-		for _, t := range e.tables {
-			C.sg_metric_tables_release(t)
+		for _, te := range e.tables { // the cache's references; calls in flight hold their own
+			C.sg_metric_tables_release(te.t)
 		}
 		e.tables = nil
 		e.tmu.Unlock()
@@ -463,23 +478,29 @@ type tablesKey struct {
 }
 
 // tablesFor tabulates an opaque metric.Metric (pkg/metric/metric.go:7-16) at one similarity for queries of up to aMax n-grams
-// (rounded up to a power of two, so that a handful of table sets serve every query length): MinY, MaxY, Threshold and the
-// score 1 - Distance exactly as metricScorer.Score computes it (pkg/suggest/scorer.go:29-31) — sg_metric_tables_create.
-// Cached per (metric value, similarity, aMax) when the metric's dynamic type is comparable; released with the index.
+// (rounded up to a power of two, so that a handful of table sets serve every query length; capped at maxTableTerms): MinY, MaxY,
+// Threshold and the score 1 - Distance exactly as metricScorer.Score computes it (pkg/suggest/scorer.go:29-31) —
+// sg_metric_tables_create.  The caller OWNS one reference of what it gets and gives it back with releaseTables when its call
+// has returned.  Sets of metrics whose dynamic type is comparable are cached per (metric value, similarity, aMax), at most
+// maxTableSets of them (least recently used out first: a metric built per request, or a similarity that varies per request,
+// costs a rebuild, not HBM); the others live for their one call.
 func (e *engine) tablesFor(m metric.Metric, sim float64, terms int) (*C.sg_metric_tables, error) {
 	aMax := 16
-	for aMax < terms {
+	for aMax < terms && aMax < maxTableTerms {
 		aMax <<= 1
 	}
 	key := tablesKey{m, sim, aMax}
 	cacheable := reflect.TypeOf(m).Comparable()
 	if cacheable {
 		e.tmu.Lock()
-		t := e.tables[key]
-		e.tmu.Unlock()
-		if t != nil {
-			return t, nil
+		if te := e.tables[key]; te != nil {
+			e.tclock++
+			te.used = e.tclock
+			C.sg_metric_tables_retain(te.t) // the caller's reference, taken under the lock: eviction cannot slip in between
+			e.tmu.Unlock()
+			return te.t, nil
 		}
+		e.tmu.Unlock()
 	}
 	S, nA := e.segments, aMax+1
 	minY, maxY := make([]C.int32_t, nA), make([]C.int32_t, nA)
@@ -525,17 +546,43 @@ func (e *engine) tablesFor(m metric.Metric, sim float64, terms int) (*C.sg_metri
 	if err != nil {
 		return nil, err
 	}
-	if cacheable {
-		e.tmu.Lock()
-		if old := e.tables[key]; old != nil { // somebody else was faster
-			e.tmu.Unlock()
-			C.sg_metric_tables_release(t)
-			return old, nil
-		}
-		e.tables[key] = t
-		e.tmu.Unlock()
+	if !cacheable {
+		return t, nil // the caller's only reference: gone with releaseTables
 	}
+	e.tmu.Lock()
+	defer e.tmu.Unlock()
+	if e.tables == nil { // closed meanwhile: nothing is cached any more
+		return t, nil
+	}
+	if old := e.tables[key]; old != nil { // somebody else was faster: theirs is the cached one
+		C.sg_metric_tables_release(t)
+		e.tclock++
+		old.used = e.tclock
+		C.sg_metric_tables_retain(old.t)
+		return old.t, nil
+	}
+	if len(e.tables) >= maxTableSets { // the least recently used set gives up the cache's reference
+		var oldest tablesKey
+		first := true
+		for k, te := range e.tables {
+			if first || te.used < e.tables[oldest].used {
+				oldest, first = k, false
+			}
+		}
+		C.sg_metric_tables_release(e.tables[oldest].t)
+		delete(e.tables, oldest)
+	}
+	e.tclock++
+	e.tables[key] = &tableEntry{t: t, used: e.tclock}
+	C.sg_metric_tables_retain(t) // the cache's reference beside the caller's
 	return t, nil
+}
+
+// releaseTables gives a call's reference of a table set back (nil: the metric had a device twin, there were no tables).
+func releaseTables(t *C.sg_metric_tables) {
+	if t != nil {
+		C.sg_metric_tables_release(t)
+	}
 }
 
 // fuzzyK recovers k from a fuzzy collector-manager factory (the closure hides it, pkg/suggest/collector.go:143-149): a
@@ -606,6 +653,7 @@ func (i *Index) Suggest(query string, similarity float64, m metric.Metric, facto
 			return nil, err
 		}
 		tables = t
+		defer releaseTables(t) // (after the answer is here: the request below is answered before Suggest returns)
 	}
 	mgr := factory()
 	if _, fuzzy := mgr.(*suggest.FuzzyCollectorManager); !fuzzy {
@@ -812,6 +860,7 @@ func (i *Index) SuggestBatch(queries []string, similarity float64, m metric.Metr
 		if tables, err = i.e.tablesFor(m, similarity, longest+16); err != nil {
 			return nil, nil, err
 		}
+		defer releaseTables(tables)
 	}
 	cands, status, err = i.e.suggestBatch(queries, similarity, code, tables, k)
 	runtime.KeepAlive(i)

@@ -157,6 +157,7 @@ int sg_autocomplete_batch_from(sg_index* index, const uint8_t* q_utf8, const uin
 typedef struct sg_metric_tables sg_metric_tables;
 int sg_metric_tables_create(sg_index* index, uint32_t a_max, const int32_t* min_y, const int32_t* max_y,
                             const int32_t* threshold, const double* score, sg_metric_tables** out);
+void sg_metric_tables_retain(sg_metric_tables* tables);   /* one reference per user: a cache entry, a call in flight ([r5]) */
 void sg_metric_tables_release(sg_metric_tables* tables);
 /* sg_suggest_batch under a tabulated metric: same rows, same order. */
 int sg_suggest_batch_tables(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q,
@@ -166,7 +167,11 @@ int sg_suggest_batch_tables(sg_index* index, const uint8_t* q_utf8, const uint64
  * (suggester.go:78-99; the fuzzy top-k manager is only the usual one).  For a binding that must serve another collector:
  * row i = the `limit` smallest docIDs >= first_doc among query i's candidates over all admissible segments, ascending,
  * with their scores and (out_aux, may be NULL) segment << 16 | overlap — enough to rebuild
- * merger.MergeCandidate{Position, Overlap} and the segment's scorer.  Page with first_doc = last docID of a full page + 1.
+ * merger.MergeCandidate{Position, Overlap} and the segment's scorer.
+ * Paging: a document that repeats a term has SEVERAL entries (same docID, one per secondary candidate), and a full page may
+ * end inside such a run.  Resume with first_doc = the LAST docID of the full page (not + 1) and drop, from the head of the next
+ * page, as many entries of that docID as the pages so far have already delivered; if a whole page consists of one docID, ask
+ * again with twice the limit.  (first_doc = last docID + 1 loses the rest of the run.)  A page that comes back short is the last.
  * `tables` non-NULL replaces (metric, similarity). */
 int sg_suggest_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t* q_offs, uint32_t n_q, int metric,
                           double similarity, const sg_metric_tables* tables, uint32_t first_doc, uint32_t limit,
@@ -298,6 +303,11 @@ int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, 
 /* Test hook: the permutation the device's restatement of Go 1.14 sort.Sort (it orders equal-length posting lists in
  * cpMerge.Merge, cp_merge.go:24) gives n <= 128 keys; out[i] = original index of the element that ends at position i. */
 int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* out);
+/* [r5] The auto-tuner's choices (no GPU needed): out = {log2 of the LDS counter words, filter level, 1 if the plan -> stream ->
+ * verify pipeline pays} for an index whose queries are expected to stream est_query_chunks 16-byte chunks of u32 postings and
+ * whose longest term holds max_term_chunks; and the same for a built index together with its two statistics. */
+int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[3]);
+int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[3]);
 
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
  * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_PRETOK, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */

@@ -69,7 +69,9 @@ class MetricTables:
 def _max_terms(offs, description):
     """upper bound of the n-grams of the longest query of a batch (bytes + wrap runes)"""
     longest = int((offs[1:] - offs[:-1]).max()) if len(offs) > 1 else 0
-    return longest + len(description.wrap[0]) + len(description.wrap[1]) + 1
+    # (capped: the tables are dense — (a_max + 1)^2 x segments doubles — and filled by a Python loop; a longer query comes back
+    #  SG_COUNT_TOO_LONG from a tabulated launch)
+    return min(256, longest + len(description.wrap[0]) + len(description.wrap[1]) + 1)
 
 
 class Ticket:

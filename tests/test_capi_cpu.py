@@ -165,3 +165,45 @@ def test_loader_rejects_bad_inputs(golden_dir, tmp_path):
 def test_cdb_dictionary_matches_the_source_lines(cars_lines, golden_dir):
     from suggest_amd.service import read_cdb_dictionary
     assert read_cdb_dictionary(os.path.join(golden_dir, "db", "cars.cdb")) == cars_lines
+
+
+def test_tuner_choices_are_pinned(cars_lines, words_lines):
+    """[r5] The auto-tuner's choices (counter words, filter table, pipeline) for the dictionaries they were measured on — rounds 2-3
+    shipped the wrong filter table for three regimes unnoticed.  The statistics of the large synthetic dictionaries are the ones
+    the GPU box printed (SG_VERBOSE: expected query volume / longest term, in 16-byte chunks of u32 postings); the reference's own
+    dictionaries and a 200 k synthetic one are built here and their statistics recomputed."""
+    import ctypes as C
+    from suggest_amd import NGramIndex, IndexDescription, synth, _lib
+    L = _lib.lib()
+
+    def choice(est, longest):
+        out = (C.c_int32 * 3)()
+        _lib.check(L.sg_debug_tune_choice(float(est), float(longest), out))
+        return {"log2_cnt": out[0], "level": out[1], "pipe": out[2]}
+
+    measured = {   # dictionary: (expected query volume, longest term) -> what every sweep since round 4 found best (DESIGN.md §4 knobs)
+        "headline 10M q=3": ((21500, 2520), dict(log2_cnt=11, level=4, pipe=1)),
+        "families 10M q=3": ((21536, 2527), dict(log2_cnt=11, level=4, pipe=1)),
+        "cfg2 1M q=3": ((2316, 272), dict(log2_cnt=11, level=4, pipe=0)),
+        "cfg4 10M q=2": ((826904, 78375), dict(log2_cnt=11, level=4, pipe=0)),
+        "skewed 10M q=3": ((583089, 443397), dict(log2_cnt=12, level=4, pipe=0)),
+        "cfg5 vocabulary": ((1219, 397), dict(log2_cnt=11, level=2, pipe=0)),
+        "cars": ((790, 390), dict(log2_cnt=11, level=2, pipe=0)),
+        "words": ((5280, 3639), dict(log2_cnt=11, level=2, pipe=0)),
+    }
+    for name, ((est, longest), want) in measured.items():
+        assert choice(est, longest) == want, name
+
+    def built(ix):
+        st, out = (C.c_double * 2)(), (C.c_int32 * 3)()
+        with ix._use() as h:
+            _lib.check(L.sg_debug_tune_index(h, st, out))
+        return (st[0], st[1]), {"log2_cnt": out[0], "level": out[1], "pipe": out[2]}
+
+    (est, longest), got = built(NGramIndex(cars_lines, _desc(CARS_DESC), upload=False))
+    assert 600 < est < 1000 and 300 < longest < 500 and got == measured["cars"][1], (est, longest, got)
+    (est, longest), got = built(NGramIndex(words_lines, _desc(WORDS_DESC), upload=False))
+    assert 4000 < est < 6500 and 3000 < longest < 4200 and got == measured["words"][1], (est, longest, got)
+    blob, offs = synth.make_dict(200000, seed=1)      # uniform strings: the longest term a tenth of a query's volume, like the headline
+    (est, longest), got = built(NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION), upload=False))
+    assert 450 < est < 800 and longest < 0.25 * est and got == dict(log2_cnt=11, level=4, pipe=0), (est, longest, got)
