@@ -38,3 +38,37 @@ def test_cpp_mirror_queries_during_index_swaps_stress():
     r = subprocess.run([_binary(), GOLDEN], capture_output=True, text=True, timeout=900, env=dict(os.environ, SG_STRESS="150"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 failed" in r.stdout
+
+
+TWIN = os.path.join(CPP, "_build", "shim_twin_test")
+
+
+@pytest.mark.gpu
+def test_shim_call_sequences_from_a_compiled_host():
+    """[r5] go/suggesthip/suggesthip.go has never met a Go compiler: tests/cpp/shim_twin_test.cpp makes the same calls in the same
+    order from C++ — the pipelined dispatcher over pinned slots and two tickets, a foreign metric.Metric as tables with the cache's
+    and the calls' references, every candidate paged through sg_suggest_batch_from into a foreign collector, k discovery, Close
+    while callers are in flight (pkg/suggest/service_test.go:36-79, collector.go:136-191)."""
+    _binary()
+    r = subprocess.run([TWIN, GOLDEN, "--stress", "12"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_shim_call_sequences_under_the_sanitizers(san):
+    """the same program built with -fsanitize=address,undefined / thread (the reference runs its tests under the race detector,
+    SURVEY.md §5).  The host layer of libsuggest_hip.so is not instrumented, so this covers the caller's side of the ABI contract:
+    buffers alive until the wait returns, no row written past a slot, no race on what the caller owns."""
+    subprocess.run(["make", "-C", CPP, "sanitizers"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", TSAN_OPTIONS="report_bugs=1:halt_on_error=0:suppressions=" + os.path.join(CPP, "tsan.supp"))
+    import shutil
+    cmd = [TWIN + "_" + san, GOLDEN, "--stress", "4"]
+    if san == "tsan" and shutil.which("setarch"):            # (ThreadSanitizer wants its fixed mappings: no address-space randomisation)
+        cmd = ["setarch", "x86_64", "-R"] + cmd
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0 and not r.stdout and ("unexpected memory mapping" in r.stderr or "Shadow memory range interleaves" in r.stderr or "setarch" in r.stderr):
+        pytest.skip("the sanitizer runtime cannot map its shadow on this box: " + r.stderr[-200:])
+    assert " 0 failed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-3000:]
