@@ -291,6 +291,35 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     sc = [x.cpu().numpy() for x in d_sc]
     cnt = [x.cpu().numpy().view(np.uint32) for x in d_cnt]
 
+    # ---- N > 1: every rank holds a sample of ITS OWN rows (its own batch, its own GPU, its own replica of the index) against the
+    #      CPU oracle, and the ranks the RCCL group really spans are listed: a run nobody can watch checks itself ----
+    parity_ranks, rccl_ranks = None, None
+    if world > 1:
+        ok_n = torch.zeros(2, dtype=torch.float64)
+        try:
+            import oracle
+            n_s = int(min(n_q, 512))
+            ora = oracle.OracleIndex(blob=blob, offs=offs, **desc_kw)
+            qb, qo = batches[0]
+            oi, os_, oc, _ = ora.suggest_batch(qb[:int(qo[n_s])], qo[:n_s + 1], w["metric"], w["similarity"], k, threads=max(1, (os.cpu_count() or 1) // world))
+            valid = np.arange(k)[None, :] < np.minimum(oc, k)[:, None]
+            same = np.array_equal(cnt[0][:n_s], oc) and np.array_equal(ids[0][:n_s][valid], oi[valid]) and \
+                np.array_equal(sc[0][:n_s].view(np.uint64)[valid], os_.view(np.uint64)[valid])
+            ok_n[0], ok_n[1] = n_s, 1.0 if same else 0.0
+            del ora
+        except Exception as exc:
+            log("rank %d: oracle check failed to run: %r" % (rank, exc))
+        every = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, ok_n)                                 # (gloo)
+        parity_ranks = [{"rank": r, "checked_queries": int(x[0].item()), "bit_exact": bool(x[1].item() == 1.0) if x[0].item() else None} for r, x in enumerate(every)]
+        if env.nccl_group is not None:
+            try:
+                seen = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
+                dist.all_gather(seen, torch.tensor([rank], dtype=torch.int32, device=dev), group=env.nccl_group)
+                rccl_ranks = {"group_size": int(dist.get_world_size(group=env.nccl_group)), "ranks": [int(x.item()) for x in seen]}
+            except Exception as exc:
+                rccl_ranks = {"error": repr(exc)}
+
     # ---- the host-buffer entry point (what a cgo caller uses): PCIe-inclusive, never the headline value ----
     host = None
     if rank == 0 and world == 1 and host_rate:
@@ -497,6 +526,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "parallelism": "query-sharded x%d, index replica per GPU, one process per GPU%s"
                                   % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
                    "rccl_gather_check": gather_ok,
+                   "rccl_ranks": rccl_ranks,          # the ranks the RCCL group spans, as all-gathered over it (N > 1)
+                   "parity_per_rank": parity_ranks,   # every rank's own rows against the CPU oracle on a sample (N > 1)
                    "gather_ms": gather_ms,       # the optional all_gather of one step's result rows (3 collectives, k*(u32,f64)+u32 per query), max over ranks, untimed region
                    "per_rank": per_rank,
                    "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],

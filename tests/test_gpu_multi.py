@@ -192,6 +192,9 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec["roofline"]["frac"] is None or 0 < rec["roofline"]["frac"] <= 1
     rm = rec["replicas_mode"]                       # rank 0's single-process leg: sg_index_replicate + sg_suggest_batch_multi
     assert rm["n_gpus"] == 2 and rm["rows_equal_device_run"] is True and rm["value"] > 0
+    # [r5] every rank checks a sample of its OWN rows against the CPU oracle (nobody watches an 8-GPU run)
+    pr = rec["config"]["parity_per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["checked_queries"] > 0 and x["bit_exact"] is True for x in pr), pr
 
 
 def test_bench_self_spawns_two_ranks():
