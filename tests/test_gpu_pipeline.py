@@ -69,15 +69,21 @@ def test_candidate_overflow_goes_to_the_fused_kernel(synth_pipe):
 
 
 def test_plan_hands_back_what_it_cannot_express(synth_pipe):
-    """the smallest counter array: single segments that need docID-range passes are the fused kernel's"""
+    """the smallest counter array and the strictest filter table: single segments outnumber the counters — up to SG_PIPE_LOOSE
+    times they are planned on the full array anyway (more flagged postings, same matches), beyond that and for queries above 64
+    n-grams the plan lists the query for the fused kernel; the rows must not tell which"""
+    from suggest_amd import pack_strings
     gpu, ora, qb, qo = synth_pipe
+    qs = [qb[int(qo[i]):int(qo[i + 1])].tobytes() for i in range(2500)]
+    long_ones = [(qs[i] + qs[i + 100] + qs[i + 200] + qs[i + 300] + qs[i + 400])[:75 + i % 25] for i in range(60)]   # 75 .. 99 bytes of distinct n-grams: above 64, below 128
+    b2, o2 = pack_strings(qs + long_ones)
     try:
         gpu.tune(SG_PIPE_LOG2_CNT=9, SG_FILTER_LEVEL=0)
-        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.3, k=10))
+        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=b2, offs=o2, metric="cosine", similarity=0.3, k=10))
     finally:
         gpu.tune(SG_PIPE_LOG2_CNT=13, SG_FILTER_LEVEL=4)
-    assert_same(res, ora.suggest_batch(qb, qo, "cosine", 0.3, 10))
-    assert d["unplanned"] > 0, d
+    assert_same(res, ora.suggest_batch(b2, o2, "cosine", 0.3, 10))
+    assert d["unplanned"] >= len(long_ones), d
 
 
 def test_documents_that_repeat_a_term_and_near_duplicates():
