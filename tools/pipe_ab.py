@@ -33,7 +33,7 @@ d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to
 d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-NAMES = dict(nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
+NAMES = dict(cls="SG_PIPE_CLS", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
              level="SG_FILTER_LEVEL", floor="SG_T_FLOOR")
 
 
@@ -66,9 +66,10 @@ for var in args.variants.split(";"):
             a, b = kv.split("=")
             kn[NAMES[a]] = int(b)
     ix.tune(**kn)
-    ps0 = ix.pipe_stats()
+    ps0 = ix.pipe_stats(); ls0 = ix.launch_stats()
     ms, res = measure(var)
-    ps1 = ix.pipe_stats()
+    ps1 = ix.pipe_stats(); ls1 = ix.launch_stats()
+    print("   chunks streamed per sampled query: %.0f" % ((ls1["chunks"] - ls0["chunks"]) / max(1, ls1["sampled"] - ls0["sampled"])), flush=True)
     fb = {k_: (ps1[k_] - ps0[k_]) / (args.steps + 2.0) for k_ in ps1}
     same = all(np.array_equal(x, y) for x, y in zip(res, ref))
     bad = int((res[0] != ref[0]).sum()) + int((res[1] != ref[1]).any(axis=1).sum())
