@@ -306,8 +306,8 @@ int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* ou
 /* [r5] The auto-tuner's choices (no GPU needed): out = {log2 of the LDS counter words, filter level, 1 if the plan -> stream ->
  * verify pipeline pays} for an index whose queries are expected to stream est_query_chunks 16-byte chunks of u32 postings and
  * whose longest term holds max_term_chunks; and the same for a built index together with its two statistics. */
-int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[3]);
-int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[3]);
+int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[6]);
+int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[6]);
 /* [r5] the class store (the document side of the prefix filter, csrc/packed_store.inc) checked against the main store and the
  * forward index on the host (small dictionaries): out = {classes, tail ranks per class, chunks, postings, main chunks, main
  * postings, lists that differ, postings in the wrong class}; all zero when the replica has no class store */

@@ -177,28 +177,33 @@ def test_tuner_choices_are_pinned(cars_lines, words_lines):
     L = _lib.lib()
 
     def choice(est, longest):
-        out = (C.c_int32 * 3)()
+        out = (C.c_int32 * 6)()
         _lib.check(L.sg_debug_tune_choice(float(est), float(longest), out))
-        return {"log2_cnt": out[0], "level": out[1], "pipe": out[2]}
+        return {"log2_cnt": out[0], "level": out[1], "pipe": out[2], "stream": tuple(out[3:6])}
 
+    BIG, MID, SMALL = (8, 13, 8192), (4, 12, 4096), (2, 11, 2048)
     measured = {   # dictionary: (expected query volume, longest term) -> what every sweep since round 4 found best (DESIGN.md §4 knobs)
-        "headline 10M q=3": ((21500, 2520), dict(log2_cnt=11, level=4, pipe=1)),
-        "families 10M q=3": ((21536, 2527), dict(log2_cnt=11, level=4, pipe=1)),
-        "cfg2 1M q=3": ((2316, 272), dict(log2_cnt=11, level=4, pipe=0)),
-        "cfg4 10M q=2": ((826904, 78375), dict(log2_cnt=11, level=4, pipe=0)),
-        "skewed 10M q=3": ((583089, 443397), dict(log2_cnt=12, level=4, pipe=0)),
-        "cfg5 vocabulary": ((1219, 397), dict(log2_cnt=11, level=2, pipe=0)),
-        "cars": ((790, 390), dict(log2_cnt=11, level=2, pipe=0)),
-        "words": ((5280, 3639), dict(log2_cnt=11, level=2, pipe=0)),
+        # stream = (wavefronts, log2 counters, descriptor bytes) of a stream workgroup (profiles/r05zj_*: 60 k ... 4 M strings)
+        "headline 10M q=3": ((21500, 2520), dict(log2_cnt=11, level=4, pipe=1, stream=BIG)),
+        "families 10M q=3": ((21536, 2527), dict(log2_cnt=11, level=4, pipe=1, stream=BIG)),
+        "4M q=3": ((9264, 1090), dict(log2_cnt=11, level=4, pipe=1, stream=MID)),
+        "2M q=3": ((4632, 545), dict(log2_cnt=11, level=4, pipe=1, stream=SMALL)),
+        "cfg2 1M q=3": ((2316, 272), dict(log2_cnt=11, level=4, pipe=1, stream=SMALL)),
+        "60k q=3": ((311, 32), dict(log2_cnt=11, level=4, pipe=1, stream=SMALL)),
+        "cfg4 10M q=2": ((826904, 78375), dict(log2_cnt=11, level=4, pipe=0, stream=BIG)),
+        "skewed 10M q=3": ((583089, 443397), dict(log2_cnt=12, level=4, pipe=0, stream=BIG)),
+        "cfg5 vocabulary": ((1219, 397), dict(log2_cnt=11, level=2, pipe=0, stream=SMALL)),
+        "cars": ((790, 390), dict(log2_cnt=11, level=2, pipe=0, stream=SMALL)),
+        "words": ((5280, 3639), dict(log2_cnt=11, level=2, pipe=0, stream=SMALL)),
     }
     for name, ((est, longest), want) in measured.items():
         assert choice(est, longest) == want, name
 
     def built(ix):
-        st, out = (C.c_double * 2)(), (C.c_int32 * 3)()
+        st, out = (C.c_double * 2)(), (C.c_int32 * 6)()
         with ix._use() as h:
             _lib.check(L.sg_debug_tune_index(h, st, out))
-        return (st[0], st[1]), {"log2_cnt": out[0], "level": out[1], "pipe": out[2]}
+        return (st[0], st[1]), {"log2_cnt": out[0], "level": out[1], "pipe": out[2], "stream": tuple(out[3:6])}
 
     (est, longest), got = built(NGramIndex(cars_lines, _desc(CARS_DESC), upload=False))
     assert 600 < est < 1000 and 300 < longest < 500 and got == measured["cars"][1], (est, longest, got)
@@ -206,4 +211,4 @@ def test_tuner_choices_are_pinned(cars_lines, words_lines):
     assert 4000 < est < 6500 and 3000 < longest < 4200 and got == measured["words"][1], (est, longest, got)
     blob, offs = synth.make_dict(200000, seed=1)      # uniform strings: the longest term a tenth of a query's volume, like the headline
     (est, longest), got = built(NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION), upload=False))
-    assert 450 < est < 800 and longest < 0.25 * est and got == dict(log2_cnt=11, level=4, pipe=0), (est, longest, got)
+    assert 450 < est < 800 and longest < 0.25 * est and got == dict(log2_cnt=11, level=4, pipe=1, stream=SMALL), (est, longest, got)

@@ -23,7 +23,9 @@ def _pair(n_docs, n_q, desc=None, seed=1, **variant):
 @pytest.fixture(scope="module")
 def synth_pipe():
     gpu, ora, qb, qo = _pair(60000, 4096)
-    gpu.tune(SG_PIPE=1)                       # every eligible launch (the default takes it only where the index's queries stream enough)
+    # every eligible launch, and the stream workgroup of the large dictionaries (eight wavefronts, 2^13 counters, 8 KB of
+    # descriptors): a dictionary of this size gets two wavefronts on 2^11 counters by default (tune_choice, capi.inc)
+    gpu.tune(SG_PIPE=1, SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_PIPE_DT_BYTES=8192)
     return gpu, ora, qb, qo
 
 
@@ -53,6 +55,19 @@ def test_rows_do_not_depend_on_the_pipeline_knobs(synth_pipe, knobs):
             assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
     finally:
         gpu.tune(**base)
+
+
+@pytest.mark.parametrize("shape", [(2, 11, 2048), (4, 12, 4096), (1, 10, 1024), (2, 11, 1024), (1, 9, 2048)])
+def test_rows_do_not_depend_on_the_stream_workgroup(synth_pipe, shape):
+    """the stream workgroups tune_choice picks for smaller dictionaries (and smaller ones still: more queries go back to the
+    fused kernel for want of descriptors)"""
+    gpu, ora, qb, qo = synth_pipe
+    try:
+        gpu.tune(SG_PIPE_NW=shape[0], SG_PIPE_LOG2_CNT=shape[1], SG_PIPE_DT_BYTES=shape[2])
+        for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20), ("overlap", 0.9, 5)):
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
+    finally:
+        gpu.tune(SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_PIPE_DT_BYTES=8192)
 
 
 def test_candidate_overflow_goes_to_the_fused_kernel(synth_pipe):
@@ -125,12 +140,14 @@ def test_pipeline_with_a_tabulated_metric(synth_pipe):
         tabs.close()
 
 
-def test_default_policy_takes_the_pipeline_where_the_queries_are_heavy_enough():
-    """the default (SG_PIPE=2): an index whose queries stream few postings keeps the fused kernel; nothing else changes"""
-    gpu, ora, qb, qo = _pair(30000, 4096, seed=21)
-    res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10))
-    assert_same(res, ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
-    assert d == {"unplanned": 0, "overflow": 0, "repeats": 0}, d
+def test_default_policy():
+    """the default (SG_PIPE=2, the stream workgroup by the index's expected query volume): a dictionary below the one-counter-
+    per-document size keeps the fused kernel, a larger one takes the pipeline with the small workgroup; the rows do not tell"""
+    for n_docs in (30000, 120000):
+        gpu, ora, qb, qo = _pair(n_docs, 4096, seed=21)
+        res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10))
+        assert_same(res, ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
+        assert d == {"unplanned": 0, "overflow": 0, "repeats": 0}, d
 
 
 # ---- the class store: the document side of the prefix filter (csrc/packed_store.inc; off by default: SG_CLS_N) ----

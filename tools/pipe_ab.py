@@ -33,7 +33,7 @@ d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to
 d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-NAMES = dict(cls="SG_PIPE_CLS", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
+NAMES = dict(cls="SG_PIPE_CLS", dt="SG_PIPE_DT_BYTES", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
              level="SG_FILTER_LEVEL", floor="SG_T_FLOOR")
 
 
@@ -75,4 +75,4 @@ for var in args.variants.split(";"):
     bad = int((res[0] != ref[0]).sum()) + int((res[1] != ref[1]).any(axis=1).sum())
     print("%s pipe %-28s: %.3f ms  %.2f M q/s  (%.3fx)  same_results=%s%s  fallback/launch: unplanned %.0f overflow %.0f repeats %.0f" %
           (args.config, var, ms, n_q / ms / 1e3, ms0 / ms, same, "" if same else "  rows differing ~%d" % bad, fb["unplanned"], fb["overflow"], fb["repeats"]), flush=True)
-ix.tune(SG_PIPE=0, SG_FILTER_LEVEL=4, SG_T_FLOOR=8)
+ix.tune(SG_PIPE=0)
