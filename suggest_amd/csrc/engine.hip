@@ -342,6 +342,23 @@ __device__ __forceinline__ AsciiTab d_ascii_tab(const DeviceIndex& ix, int lane)
 }
 // key of one n-gram of ASCII runes (all < 128), normalised like d_pack_key
 __device__ __forceinline__ uint64_t d_pack_key_ascii(const DeviceIndex& ix, const AsciiTab& tab, const uint32_t* runes, uint32_t n) {
+  if (ix.n_pad == 1u && n <= 4u) {
+    // the usual description — one pad symbol: a rune outside the alphabet is one byte of the key like any other, the key is n
+    // bytes in place (no per-lane branch over the pad string; 31 of the tokeniser's 72 us on 65 536 queries went there)
+    const uint32_t pad0 = ix.pad_sym[0];
+    uint32_t k32 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+      if (i < n) {
+        const uint32_t r = runes[i] & 127u;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)tab.lo);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)tab.hi);
+        const uint32_t v = r < 64u ? a : b;
+        k32 |= ((v >> 8) ? (v & 0xFFu) : pad0) << (8u * i);
+      }
+    }
+    return (uint64_t)k32;
+  }
   uint64_t k = 0;
   uint32_t len = 0;
   for (uint32_t i = 0; i < n; i++) {

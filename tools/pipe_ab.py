@@ -17,6 +17,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--dict-variant", default="uniform")
 ap.add_argument("--dict-size", type=int, default=0)
 ap.add_argument("--queries", type=int, default=0)
+ap.add_argument("--build", default="device")
 args = ap.parse_args()
 c = dict(bench.CONFIGS[args.config])
 if args.dict_size:
@@ -26,7 +27,7 @@ if args.queries:
 desc = dict(synth.DESCRIPTION, ngram_size=c["ngram"])
 blob, offs = synth.make_dict(c["dict_size"], seed=1, skewed="skewed" in args.dict_variant, families=3 if "families" in args.dict_variant else 0)
 qb, qo = synth.make_queries(c["queries"], blob, offs, seed=2)
-ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc), build="device")
+ix = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**desc), build=args.build)
 dev = torch.device("cuda", 0)
 k, n_q = c["topk"], c["queries"]
 d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to(dev)
