@@ -75,6 +75,10 @@ PY
   bench)        # bench <tag> [bench args]: the default bench line
     tag=$1; shift
     timeout 1500 python bench.py "$@" > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -3 $O/${tag}_bench.err; tail -c 3000 $O/${tag}_bench.json ;;
+  bench_prof)   # bench_prof <tag> [bench args]: rocprofv3 --kernel-trace --stats of a bench.py run (the summary the roofline's kernel time must agree with)
+    tag=$1; shift
+    cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/${tag}_benchprof -o run -- python $R/bench.py --no-cpu-baseline --traffic none "$@" > $O/${tag}_benchprof.json 2> $O/${tag}_benchprof.err
+    cd $R; db=$(find $O/${tag}_benchprof -name "*.db" | head -1); python tools/rocprof_summary.py $db "${tag} bench.py --no-cpu-baseline --traffic none $*" 2>/dev/null | head -30 | cut -c1-140 | tee $O/${tag}_benchprof_summary.txt ;;
   sh)           # sh <command...>: anything else
     bash -c "$*" ;;
   *) echo "unknown job $job"; exit 2 ;;
