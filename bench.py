@@ -247,7 +247,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     ls1 = index.launch_stats()
     ps1 = index.pipe_stats()
-    pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1}    # queries per call the pipeline left to the fused kernel
+    pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1 if k_ != "queries"}    # queries per call the pipeline left to the fused kernel
+    pipe_q = (ps1.get("queries", 0) - ps0.get("queries", 0)) / float(steps)                              # ... and those it took
     d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)
     # bytes the PACKED algorithm has to move per launch: 16 B x the chunks of the lists the kernel streams (the k longest are
     # skipped, 7 postings per chunk), from the kernel's own count over its sampled queries (one in 32), + queries in + rows out
@@ -533,7 +534,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
                              "build": args.build},
                    "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt])),
-                   "pipeline": {"on": pipe_on, "left_to_fused_kernel_per_call": pipe_fb}},
+                   "pipeline": {"on": pipe_on if pipe_on is not None else pipe_q > 0, "queries_per_call": pipe_q, "left_to_fused_kernel_per_call": pipe_fb}},
         "roofline": roof,
         "cpu_baseline": cpu,
     }

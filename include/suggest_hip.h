@@ -291,7 +291,8 @@ int sg_index_launch_stats(sg_index* index, uint64_t out[4]);
 /* [r5] Queries the three-launch pipeline of ordinary fuzzy batches (plan -> stream -> verify) handed to the fused
  * kernel, cumulative (wrapping at 2^32): out[0] the plan could not express them (more than 64 n-grams, a window of more than 63
  * segments, a segment that needs docID-range passes, more groups / lists than a slot record holds), [1] their candidates
- * overflowed the slots, [2] a matching document repeats a term (the secondary entries of SURVEY.md §A.3), [3] 0.
+ * overflowed the slots, [2] a matching document repeats a term (the secondary entries of SURVEY.md §A.3); [3] the queries
+ * of all launches that took the pipeline so far (not wrapping).
  * Results never depend on which path answered.  Synchronises the device. */
 int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
 

@@ -446,11 +446,11 @@ class NGramIndex:
         return {"full": int(out[0]), "sampled": int(out[1]), "results": int(out[2]), "chunks": int(out[3])}
 
     def pipe_stats(self):
-        """queries the plan -> stream -> verify pipeline left to the fused kernel (cumulative): {unplanned, overflow, repeats} — sg_index_pipe_stats"""
+        """queries the plan -> stream -> verify pipeline left to the fused kernel (cumulative): {unplanned, overflow, repeats}, and `queries`: those of all launches that took the pipeline — sg_index_pipe_stats"""
         out = (C.c_uint64 * 4)()
         with self._use() as h:
             _lib.check(_lib.lib().sg_index_pipe_stats(h, out))
-        return {"unplanned": int(out[0]), "overflow": int(out[1]), "repeats": int(out[2])}
+        return {"unplanned": int(out[0]), "overflow": int(out[1]), "repeats": int(out[2]), "queries": int(out[3])}
 
     def stats(self):
         st = _lib.SgStats()

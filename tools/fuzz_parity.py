@@ -63,6 +63,17 @@ def make_trial(seed, scale=1):
     env["SG_PRETOK"] = rng.choice(["0", "1", "1", "2048"])
     # (round 4, drawn last again) 8-bit gaps for dense terms: 2 = every term (gaps above 255 all over a sparse list: chunks of one posting)
     env["SG_G8"] = rng.choice(["0", "1", "2", "2"])
+    # (round 5, drawn last again) plan -> stream -> verify: forced / by policy / off, every stream workgroup, tiny candidate slots
+    # (overflow -> the fused kernel), the class store (the document side of the prefix filter) in several geometries
+    env["SG_PIPE"] = rng.choice(["0", "1", "1", "1", "2"])
+    env["SG_PIPE_NW"] = rng.choice(["1", "2", "4", "8"])
+    env["SG_PIPE_LOG2_CNT"] = rng.choice(["9", "10", "11", "12", "13"])
+    env["SG_PIPE_DT_BYTES"] = rng.choice(["1024", "2048", "4096", "8192"])
+    env["SG_PIPE_SUB"] = rng.choice(["3", "4", "5"])
+    env["SG_PIPE_CAND_CAP"] = rng.choice(["2", "16", "64", "64", "512"])
+    env["SG_CLS_N"] = rng.choice(["0", "0", "2", "4", "8"])
+    env["SG_CLS_SHIFT"] = rng.choice(["0", "1", "2"])
+    env["SG_PIPE_CLS"] = rng.choice(["0", "1", "1"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
@@ -113,6 +124,10 @@ def run_trial(t, verbose=False, only=None, k_override=None):
     valid = np.arange(t["limit"])[None, :] < np.minimum(oc, t["limit"])[:, None]
     if not (np.array_equal(cnt, oc) and np.array_equal(ids[valid], oi[valid])):
         out.append("autocomplete limit=%d" % t["limit"])
+    try:
+        t["pipe_queries"] = gpu.pipe_stats()["queries"]
+    except Exception:
+        t["pipe_queries"] = 0
     gpu.close()
     return out
 
@@ -123,6 +138,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--replay", type=int, default=None)
     ap.add_argument("--scale", type=int, default=1, help="multiplies the dictionary sizes (1 .. 20 000 documents)")
+    ap.add_argument("--pipe", action="store_true", help="[r5] only trials the plan -> stream -> verify launches are eligible for: dictionaries above 2 048 "
+                    "documents, k <= 64, the tokeniser launch on, no tightening / 8-bit gaps / split queries, SG_PIPE=1 (every other knob as drawn)")
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()
     import torch  # noqa: F401
@@ -135,7 +152,7 @@ def main():
         for m in run_trial(t, verbose=True, only=int(over["only"]) if "only" in over else None, k_override=int(over["k"]) if "k" in over else None):
             print("MISMATCH", m)
         return
-    t_end, trial, bad = time.time() + args.seconds, 0, 0
+    t_end, trial, bad, piped, piped_trials = time.time() + args.seconds, 0, 0, 0, 0
     while time.time() < t_end:
         seed = args.seed * 100000 + trial
         trial += 1
@@ -143,14 +160,20 @@ def main():
         t = make_trial(seed, args.scale)
         if t is None:
             continue
+        if args.pipe:
+            if len(t["docs"]) < 3000:
+                continue
+            t["env"].update(SG_PIPE="1", SG_PRETOK="1", SG_TIGHTEN="0", SG_G8="0", SG_SPLIT_CHUNKS="0", SG_LOG2_CNT="9")
+            t["searches"] = [(m_, a_, min(k_, 64)) for m_, a_, k_ in t["searches"]]
         for m in run_trial(t):
             bad += 1
             print("MISMATCH seed %d: %s env=%s build=%s: %s" % (seed, t["desc"], t["env"], t["build"], m), flush=True)
+        piped += t.get("pipe_queries", 0); piped_trials += 1 if t.get("pipe_queries", 0) else 0
         tm = t.get("timing", {"gpu": 0.0, "oracle": 0.0})
         if time.time() - t0 > 5 or tm["gpu"] > 1.0:
             print("slow trial: seed %d took %.1f s (device side %.2f s, oracle %.2f s): %s, %d docs, syms %r, searches %s, env %s"
                   % (seed, time.time() - t0, tm["gpu"], tm["oracle"], t["desc"], len(t["docs"]), t["syms"], t["searches"], t["env"]), flush=True)
-    print("fuzz: %d trials, %d mismatches" % (trial, bad))
+    print("fuzz: %d trials, %d mismatches; %d trials (%d queries) went through plan -> stream -> verify" % (trial, bad, piped_trials, piped))
     sys.exit(1 if bad else 0)
 
 
