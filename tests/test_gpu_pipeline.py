@@ -143,11 +143,11 @@ def test_pipeline_with_a_tabulated_metric(synth_pipe):
 def test_default_policy():
     """the default (SG_PIPE=2, the stream workgroup by the index's expected query volume): a dictionary below the one-counter-
     per-document size keeps the fused kernel, a larger one takes the pipeline with the small workgroup; the rows do not tell"""
-    for n_docs in (30000, 120000):
+    for n_docs in (8000, 120000):
         gpu, ora, qb, qo = _pair(n_docs, 4096, seed=21)
         res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10))
         assert_same(res, ora.suggest_batch(qb, qo, "jaccard", 0.5, 10))
-        assert d == {"unplanned": 0, "overflow": 0, "repeats": 0, "queries": 0 if n_docs == 30000 else 4096}, d
+        assert d == {"unplanned": 0, "overflow": 0, "repeats": 0, "queries": 0 if n_docs == 8000 else 4096}, d
 
 
 # ---- the class store: the document side of the prefix filter (csrc/packed_store.inc; off by default: SG_CLS_N) ----
