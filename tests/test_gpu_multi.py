@@ -324,7 +324,7 @@ def test_device_pairsort_on_the_hand_traced_vectors(reference_tests):
     import ctypes as C
     from suggest_amd import _lib
     L = _lib.lib()
-    for v in reference_tests["go_sort_small"]["vectors"]:
+    for v in reference_tests["go_sort_small"]["vectors"] + reference_tests["go_sort_mid"]["vectors"]:      # <= 12, and 13 .. 40 elements
         keys = np.array(v["keys"], dtype=np.uint32)
         out = np.zeros(len(keys), dtype=np.uint32)
         _lib.check(L.sg_debug_pairsort(0, keys.ctypes.data, len(keys), out.ctypes.data))

@@ -224,8 +224,8 @@ def test_go_sort_hand_traced_small_inputs(reference_tests):
     """Go 1.14 sort.Sort on <= 12 elements is two straight-line steps (a ShellSort pass with gap 6, then insertionSort:
     src/sort/sort.go, quickSort) — traced compare by compare in tests/golden/go_sort_small_traces.txt by a script that
     implements nothing else (tools/gosort_hand_traces.py).  Both CPU restatements of the full algorithm must give these
-    permutations; the device's PairSort is held to them in the GPU suite.  (The branches above 12 elements — ninther
-    pivot, heapSort fallback — stay pinned only by the three restatements agreeing: no Go toolchain)"""
+    permutations; the device's PairSort is held to them in the GPU suite.  (13 .. 40 elements: the next test; the ninther pivot
+    above 40 and the heapSort fallback stay pinned only by the three restatements agreeing: no Go toolchain)"""
     import numpy as np
     import gosort
     vectors = reference_tests["go_sort_small"]["vectors"]
@@ -237,3 +237,22 @@ def test_go_sort_hand_traced_small_inputs(reference_tests):
         assert gosort.go_sort(v["keys"]) == v["perm"], v
         unstable += v["perm"] != sorted(range(len(keys)), key=lambda i: (v["keys"][i], i))
     assert unstable >= 3                    # the vectors do show the instability (a stable sort would fail them)
+
+
+def test_go_sort_hand_traced_13_to_40_elements(reference_tests):
+    """[r5] 13 .. 40 elements: quickSort's loop with doPivot's median-of-three branch (no ninther: hi - lo <= 40; the inputs never
+    exhaust maxDepth, so no heapSort), pieces of <= 12 elements by the two straight-line steps — every Less and Swap written out
+    in tests/golden/go_sort_mid_traces.txt by tools/gosort_hand_traces.py, which transcribes those functions of go1.14
+    src/sort/sort.go statement by statement (quoted in its header).  Above 40 elements (ninther) and heapSort stay pinned by the
+    restatements agreeing."""
+    import numpy as np
+    import gosort
+    vectors = reference_tests["go_sort_mid"]["vectors"]
+    assert len(vectors) >= 24 and {len(v["keys"]) for v in vectors} >= {13, 14, 20, 30, 37, 40}
+    unstable = 0
+    for v in vectors:
+        assert 13 <= len(v["keys"]) <= 40
+        assert oracle.go_sort(np.array(v["keys"], dtype=np.uint32)) == v["perm"], v
+        assert gosort.go_sort(v["keys"]) == v["perm"], v
+        unstable += v["perm"] != sorted(range(len(v["keys"])), key=lambda i: (v["keys"][i], i))
+    assert unstable >= 10
