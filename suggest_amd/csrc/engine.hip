@@ -429,11 +429,11 @@ __device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, u
   if (ascii) {
     R = n_w0 + qlen + n_w1;
     if (R > SG_MAX_RUNES) return -1;
-    if ((uint32_t)lane < n_w0) runes[lane] = d_lower(ix, ix.wrap0[lane]);
-    if ((uint32_t)lane < n_w1) runes[n_w0 + qlen + lane] = d_lower(ix, ix.wrap1[lane]);
+    // (the wrap strings by uniform index: scalar reads of the kernel arguments — indexed by lane they were two vector loads from
+    //  the argument block, a memory round trip each, at the head of every query)
     byte_len = qlen;
-    for (uint32_t i = 0; i < n_w0; i++) byte_len += d_width(d_lower(ix, ix.wrap0[i]));
-    for (uint32_t i = 0; i < n_w1; i++) byte_len += d_width(d_lower(ix, ix.wrap1[i]));
+    for (uint32_t i = 0; i < n_w0; i++) { const uint32_t r = d_lower(ix, ix.wrap0[i]); if (lane == 0) runes[i] = r; byte_len += d_width(r); }
+    for (uint32_t i = 0; i < n_w1; i++) { const uint32_t r = d_lower(ix, ix.wrap1[i]); if (lane == 0) runes[n_w0 + qlen + i] = r; byte_len += d_width(r); }
   } else {
     // rare path: every lane runs the same sequential decode (uniform), lane 0 stores
     bool too_long = false;
