@@ -57,7 +57,7 @@ def test_rows_do_not_depend_on_the_pipeline_knobs(synth_pipe, knobs):
         gpu.tune(**base)
 
 
-@pytest.mark.parametrize("shape", [(2, 11, 2048), (4, 12, 4096), (1, 10, 1024), (2, 11, 1024), (1, 9, 2048)])
+@pytest.mark.parametrize("shape", [(2, 11, 2048), (4, 12, 4096), (1, 10, 1024), (2, 11, 1024), (1, 9, 2048), (8, 13, 32768)])
 def test_rows_do_not_depend_on_the_stream_workgroup(synth_pipe, shape):
     """the stream workgroups tune_choice picks for smaller dictionaries (and smaller ones still: more queries go back to the
     fused kernel for want of descriptors)"""
