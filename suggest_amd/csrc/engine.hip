@@ -2791,10 +2791,13 @@ __global__ __launch_bounds__(1024) void query_order_count_kernel(const uint64_t*
   __syncthreads();
   if (i < n_q && (!flag || flag[i])) atomicAdd(&hist[d_order_bin(q_offs, q_len, i, shortest_first)], 1u);
   __syncthreads();
-  if (tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
+  // (direct path: the blocks' own histograms are all the scatter launch needs — no atomics on the batch's, whose words then
+  //  need no memset launch in front of this one)
+  if (!blk_hist && tid < 256u && hist[tid]) atomicAdd(ctl + 4 + tid, hist[tid]);
   if (blk_hist && tid < 256u) blk_hist[blockIdx.x * 256u + tid] = hist[tid];
   if (i == 0u) {
     ctl[0] = n_q;
+    if (blk_hist) { ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u; }     // (ctl[1]: the pipeline's count of queries left to the fused kernel)
     // [r5] the call's other control words (the list of queries for sg_long_kernel, the pipeline's list for the fused kernel): zeroed
     // here, ahead of the launches that append to them, instead of by a memset launch each
     if (zero0) *zero0 = 0u;
@@ -2810,17 +2813,26 @@ __global__ __launch_bounds__(1024) void query_order_scatter_kernel(const uint64_
   const bool mine = i < n_q && (!flag || flag[i]);
   const uint32_t bin = mine ? d_order_bin(q_offs, q_len, i, shortest_first) : 0u;
   if (mine) atomicAdd(&hist[bin], 1u);
-  const uint32_t g = tid < 256u ? ctl[4 + tid] : 0u;          // the whole batch's count of this length
-  uint32_t before = 0;                                         // ... and the blocks' before this one (direct path)
-  if (blk_hist && tid < 256u) for (uint32_t b = 0; b < blockIdx.x; b++) before += blk_hist[b * 256u + tid];
+  // the whole batch's count of every length, and the blocks' before this one: four threads per length, a quarter of the blocks each
+  __shared__ uint32_t tot[256], bef[256];
+  if (tid < 256u) { tot[tid] = blk_hist ? 0u : ctl[4 + tid]; bef[tid] = 0u; }
+  __syncthreads();
+  if (blk_hist) {
+    uint32_t gp = 0, bp = 0;
+    for (uint32_t b = tid >> 8; b < gridDim.x; b += 4u) { const uint32_t c = blk_hist[b * 256u + (tid & 255u)]; gp += c; bp += b < blockIdx.x ? c : 0u; }
+    if (gp) atomicAdd(&tot[tid & 255u], gp);
+    if (bp) atomicAdd(&bef[tid & 255u], bp);
+  }
+  __syncthreads();
+  const uint32_t g = tid < 256u ? tot[tid] : 0u, before = tid < 256u ? bef[tid] : 0u;
   if (tid < 256u) start[tid] = g;
   __syncthreads();
-  for (uint32_t off = 1; off < 256u; off <<= 1) {              // inclusive scan over the lengths
-    const uint32_t v = (tid < 256u && tid >= off) ? start[tid - off] : 0u;
-    __syncthreads();
-    if (tid < 256u) start[tid] += v;
-    __syncthreads();
+  if (tid < 64u) {                                             // inclusive scan over the lengths: four per lane, one wave scan
+    const uint32_t c0 = start[4u * tid], c1 = start[4u * tid + 1u], c2 = start[4u * tid + 2u], c3 = start[4u * tid + 3u];
+    const uint32_t sum = c0 + c1 + c2 + c3, excl = wave_scan_incl(sum, (int)tid) - sum;
+    start[4u * tid] = excl + c0; start[4u * tid + 1u] = excl + c0 + c1; start[4u * tid + 2u] = excl + c0 + c1 + c2; start[4u * tid + 3u] = excl + sum;
   }
+  __syncthreads();
   if (flag && blockIdx.x == 0u && tid == 255u) ctl[0] = start[255];   // the subset's size (nobody reads ctl[0] before the search launch)
   if (tid < 256u) {
     const uint32_t c = hist[tid], base = start[tid] - g;
