@@ -213,3 +213,17 @@ def test_class_store_with_repeated_query_terms_and_a_tabulated_metric():
         assert_same(gpu.suggest_batch(blob=qb, offs=qo, k=10, tables=tabs), ora.suggest_batch(qb, qo, "dice", 0.6, 10))
     finally:
         tabs.close()
+
+
+def test_a_batch_above_the_direct_ordering_limit():
+    """more than 128 blocks of 1024 queries: the ordering launches keep their batch-wide histogram (atomics + memset) instead of
+    summing the blocks' own (engine.hip query_order_*); ordered or not, fused kernel or pipeline, the rows are the oracle's"""
+    gpu, ora, qb, qo = _pair(120000, 140000, seed=31)
+    want = ora.suggest_batch(qb, qo, "jaccard", 0.5, 10)
+    try:
+        for order in (1, 0):
+            for pipe in (1, 0):
+                gpu.tune(SG_ORDER=order, SG_PIPE=pipe)
+                assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.5, k=10), want)
+    finally:
+        gpu.tune(SG_ORDER=1, SG_PIPE=2)
