@@ -296,6 +296,12 @@ int sg_index_launch_stats(sg_index* index, uint64_t out[4]);
  * Results never depend on which path answered.  Synchronises the device. */
 int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
 
+/* [r6] The pipeline's sampled volumes, cumulative (wrapping at 2^32): out[0] sampled queries the plan expressed (one in 32 of a batch
+ * above 1 024 queries, else every one), [1] their groups of cardinality segments, [2] streamed lists, [3] rows of 64 lanes,
+ * [4] candidates pushed for the sampled queries that reached the verify launch, [5..7] 0.  Introspection for bench.py and the
+ * tuner's tests; no reference counterpart.  Synchronises the device. */
+int sg_index_pipe_volumes(sg_index* index, uint64_t out[8]);
+
 /* The forward index (doc -> distinct terms) of the primary replica, copied back for documents
  * first .. first+n-1: out_card[i] = cardinality, out_n[i] = number of distinct terms, out_keys[i*cap ..] their term keys. */
 int sg_index_forward(sg_index* index, uint32_t first, uint32_t n, uint32_t cap, uint32_t* out_card, uint32_t* out_n,

@@ -25,7 +25,7 @@ EXPORTS = [
     "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one", "sg_autocomplete_one_from", "sg_autocomplete_batch_from",
     "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort", "sg_debug_tune_choice", "sg_debug_tune_index", "sg_debug_class_store",
     "sg_host_alloc", "sg_host_free", "sg_suggest_submit", "sg_suggest_submit_on", "sg_autocomplete_submit", "sg_ticket_wait",
-    "sg_metric_tables_create", "sg_metric_tables_retain", "sg_metric_tables_release", "sg_suggest_batch_tables", "sg_suggest_batch_from", "sg_index_launch_stats", "sg_index_pipe_stats",
+    "sg_metric_tables_create", "sg_metric_tables_retain", "sg_metric_tables_release", "sg_suggest_batch_tables", "sg_suggest_batch_from", "sg_index_launch_stats", "sg_index_pipe_stats", "sg_index_pipe_volumes",
 ]
 SG_COUNT_LM_ERROR = 0xFFFFFFFC
 
@@ -130,6 +130,7 @@ def lib():
     if hasattr(L, "sg_ticket_wait"): L.sg_ticket_wait.argtypes = [vp]
     if hasattr(L, "sg_index_launch_stats"): L.sg_index_launch_stats.argtypes = [vp, vp]
     if hasattr(L, "sg_index_pipe_stats"): L.sg_index_pipe_stats.argtypes = [vp, vp]
+    if hasattr(L, "sg_index_pipe_volumes"): L.sg_index_pipe_volumes.argtypes = [vp, vp]
     if hasattr(L, "sg_metric_tables_create"): L.sg_metric_tables_create.argtypes = [vp, u32, vp, vp, vp, vp, C.POINTER(vp)]
     if hasattr(L, "sg_metric_tables_retain"): L.sg_metric_tables_retain.argtypes = [vp]
     if hasattr(L, "sg_metric_tables_retain"): L.sg_metric_tables_retain.restype = None

@@ -2856,7 +2856,7 @@ __global__ __launch_bounds__(256) void host_store_kernel(const HostStoreArgs h) 
 
 // the sampled fill counters (BatchArgs::fill_stat) -> mapped host memory (see launch())
 __global__ void fill_stat_copy_kernel(const uint32_t* src, uint32_t* dst_host) {
-  if (threadIdx.x < 8u) dst_host[threadIdx.x] = src[threadIdx.x];     // (words 3, 6, 7: what the pipeline left to the fused kernel)
+  if (threadIdx.x < 16u) dst_host[threadIdx.x] = src[threadIdx.x];    // (words 3, 6, 7: what the pipeline left to the fused kernel; 8 .. 12: its sampled volumes)
 }
 
 // test hook (sg_debug_pairsort): the device's restatement of Go 1.14 sort.Sort on arbitrary keys — a differential fuzz

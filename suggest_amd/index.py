@@ -452,6 +452,13 @@ class NGramIndex:
             _lib.check(_lib.lib().sg_index_pipe_stats(h, out))
         return {"unplanned": int(out[0]), "overflow": int(out[1]), "repeats": int(out[2]), "queries": int(out[3])}
 
+    def pipe_volumes(self):
+        """the pipeline's sampled volumes (cumulative): {sampled, groups, lists, rows, candidates} — sg_index_pipe_volumes"""
+        out = (C.c_uint64 * 8)()
+        with self._use() as h:
+            _lib.check(_lib.lib().sg_index_pipe_volumes(h, out))
+        return {"sampled": int(out[0]), "groups": int(out[1]), "lists": int(out[2]), "rows": int(out[3]), "candidates": int(out[4])}
+
     def stats(self):
         st = _lib.SgStats()
         with self._use() as h:

@@ -79,6 +79,26 @@ PY
     tag=$1; shift
     cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/${tag}_benchprof -o run -- python $R/bench.py --no-cpu-baseline --traffic none "$@" > $O/${tag}_benchprof.json 2> $O/${tag}_benchprof.err
     cd $R; db=$(find $O/${tag}_benchprof -name "*.db" | head -1); python tools/rocprof_summary.py $db "${tag} bench.py --no-cpu-baseline --traffic none $*" 2>/dev/null | head -30 | cut -c1-140 | tee $O/${tag}_benchprof_summary.txt ;;
+  plan_stages)  # plan_stages <tag> <config> <variant>: [r6] the plan / verify launches cut short behind stage n (SG_PHASE_TIMING build): where their time goes
+    tag=$1; cfg=$2; var=$3; shift 3
+    make -C suggest_amd/csrc prof > /dev/null 2>&1 || exit 1
+    cd /tmp
+    for skip in 0 1048576 2097152 3145728 4194304 16777216 33554432 50331648 67108864; do
+      rm -rf /tmp/ps_prof
+      SG_LIB_NAME=libsuggest_hip_prof.so SG_DEBUG_SKIP=$skip timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ps_prof -- python $R/tools/pipe_ab.py --config $cfg --variants "$var" --steps 10 --no-fused "$@" > /tmp/ps.log 2>&1
+      python - $skip <<'PY'
+import csv, glob, sys
+per = {}
+for p in glob.glob("/tmp/ps_prof/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        n = r["Kernel_Name"]
+        for key in ("sg_plan_kernel", "sg_verify_kernel", "sg_stream_kernel", "query_order_count", "query_order_scatter"):
+            if key in n:
+                per.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+skip = int(sys.argv[1])
+print("plan stage %d verify stage %d: " % ((skip >> 20) & 15, (skip >> 24) & 15) + "  ".join("%s %.1f us (n=%d)" % (k, sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) / 1e3, len(v)) for k, v in sorted(per.items())))
+PY
+    done 2>&1 | tee $O/${tag}_plan_stages_${cfg}.txt ;;
   sh)           # sh <command...>: anything else
     bash -c "$*" ;;
   *) echo "unknown job $job"; exit 2 ;;
