@@ -64,8 +64,9 @@ WORKLOAD_KEYS = ("dict_size", "queries", "ngram", "metric", "similarity", "topk"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of ~0.3 s at the headline, so that "
+                                                            "run-to-run differences of a few per cent are above the noise; the spread is in roofline.kernel_ms_*)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS) + ["cfg5"],
                     help="BASELINE.json config (default: the one the metric is quoted on); explicit flags below override it")
     ap.add_argument("--mode", default="procs", choices=["procs", "replicas"],
@@ -78,16 +79,18 @@ def parse_args(argv=None):
     ap.add_argument("--similarity", type=float, default=None)
     ap.add_argument("--topk", type=int, default=None)
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the steps rotate over")
-    ap.add_argument("--dict-variant", default="uniform", choices=["uniform", "skewed", "families", "skewed-families"],
-                    help="SURVEY.md §8d dictionary variants (headline = uniform); families = base + 3 edited copies")
+    ap.add_argument("--dict-variant", default="uniform", choices=["uniform", "skewed", "families", "skewed-families", "words"],
+                    help="SURVEY.md §8d dictionary variants (headline = uniform); families = base + 3 edited copies; words = the reference's "
+                         "235 887-word test dictionary (tests/golden/words.dict.xz, its own index description), --dict-size ignored")
     ap.add_argument("--build", default="device", choices=["device", "host"],
                     help="index build: on the GPU (sg_index_build_device, 0.4 s at 10M; the posting store stays where it was "
                          "built) or on the host (sg_index_build, then uploaded); same arrays either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
     ap.add_argument("--sub-configs", default="auto",
-                    help="comma list of BASELINE configs measured after the main one and reported under `configs` "
-                         "(auto = cfg2,cfg3,cfg4 for the plain default run at N=1, none otherwise; 'none' = off)")
+                    help="comma list of configs measured after the main one and reported under `configs`: BASELINE's cfg2..cfg5, and the "
+                         "result-dense workloads families / words / skewed "
+                         "(auto = cfg3,cfg4,skewed,families,cfg2,words,cfg5 for the plain default run at N=1, none otherwise; 'none' = off)")
     ap.add_argument("--gather", action="store_true",
                     help="N>1: include the optional RCCL all_gather of the k*(u32,f64) result rows in every timed step "
                          "(default: results stay sharded — the path has no data-path collective; one untimed gather validates RCCL)")
@@ -180,25 +183,54 @@ _DICT_CACHE = {}
 _ORACLE_CACHE = {}
 
 
+WORDS_DESC = dict(ngram_size=3, wrap=("^", "$"), pad="$", alphabet=("english", "numbers", "$^"))   # (tests/conftest.py: the reference's words index)
+
+
 def get_dict(size, variant):
     from suggest_amd import synth
     key = (size, variant)
     if key not in _DICT_CACHE:
         _DICT_CACHE.clear()                                   # (one 10M dictionary at a time: ~200 MB)
-        _DICT_CACHE[key] = synth.make_dict(size, seed=1, skewed="skewed" in variant, families=3 if "families" in variant else 0)
+        if variant == "words":      # the reference's own word list: real-language n-gram lists, dozens of matches per query
+            import lzma
+            import numpy as np
+            lines = lzma.open(os.path.join(ROOT, "tests", "golden", "words.dict.xz")).read().split(b"\n")
+            if lines and lines[-1] == b"":
+                lines.pop()
+            offs = np.zeros(len(lines) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(x) for x in lines]).astype(np.uint64)
+            _DICT_CACHE[key] = (np.frombuffer(b"".join(lines), dtype=np.uint8).copy(), offs)
+        else:
+            _DICT_CACHE[key] = synth.make_dict(size, seed=1, skewed="skewed" in variant, families=3 if "families" in variant else 0)
     return _DICT_CACHE[key]
 
 
-def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traffic_mode="auto", replicas_leg=False):
+def cpu_quota():
+    """cores the container may use: the cgroup CPU quota, else the affinity mask -> (float or None, int)"""
+    quota = None
+    try:
+        q_us, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q_us == "max" else float(q_us) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        hw = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        hw = os.cpu_count() or 1
+    return quota, hw
+
+
+def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traffic_mode="auto", replicas_leg=False, parity_rows=None):
     """One workload `w` (dict of WORKLOAD_KEYS + variant) on this rank's GPU -> the record (rank 0) or None."""
     import numpy as np
     torch, dist = env.torch, env.dist
     from suggest_amd import IndexDescription, NGramIndex, synth
     rank, world, dev, log = env.rank, env.world, env.dev, env.log
-    desc_kw = dict(synth.DESCRIPTION, ngram_size=w["ngram"])
+    desc_kw = dict(WORDS_DESC if w["variant"] == "words" else synth.DESCRIPTION, ngram_size=w["ngram"])
     k, n_q, n_b = w["topk"], w["queries"], max(1, args.batches)
     t0 = time.time()
     blob, offs = get_dict(w["dict_size"], w["variant"])
+    w = dict(w, dict_size=len(offs) - 1)
     # batch b of rank r = queries [(r * n_b + b) * n_q, ...) of one deterministic stream (seed 2)
     batches = [synth.make_queries(n_q, blob, offs, seed=2, start=(rank * n_b + b) * n_q) for b in range(n_b)]
     log("[%s] dict %d strings + %d batches of %d queries generated in %.1fs" % (w["name"], w["dict_size"], n_b, n_q, time.time() - t0))
@@ -235,6 +267,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     env.barrier()
     ls0 = index.launch_stats()
     ps0 = index.pipe_stats()
+    pv0 = index.pipe_volumes()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t_start = time.perf_counter()
     for i in range(steps):
@@ -247,6 +280,9 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     ls1 = index.launch_stats()
     ps1 = index.pipe_stats()
+    pv1 = index.pipe_volumes()
+    pv_n = (pv1["sampled"] - pv0["sampled"]) % (1 << 32)
+    pipe_vol = {k_: ((pv1[k_] - pv0[k_]) % (1 << 32)) / float(pv_n) for k_ in ("groups", "lists", "rows", "candidates")} if pv_n else None
     pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1 if k_ != "queries"}    # queries per call the pipeline left to the fused kernel
     pipe_q = (ps1.get("queries", 0) - ps0.get("queries", 0)) / float(steps)                              # ... and those it took
     d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)
@@ -407,31 +443,36 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             res = ora.suggest_batch(qb[:int(qo[n])], qo[:n + 1], w["metric"], w["similarity"], k, threads=threads)
             return res, time.perf_counter() - t0
 
-        budget = 12.0 if cpu_baseline is True else float(cpu_baseline)       # seconds of wall time for the all-threads sample
-        n_s = min(args.cpu_sample or n_q, n_q)
-        if not args.cpu_sample:
-            probe = min(n_q, 2048 if budget >= 8 else 512)
-            _, dt = timed(probe, cores)
-            n_s = int(min(n_q, max(probe, probe / max(dt, 1e-6) * budget)))
-        (oi, os_, oc, used), dt = timed(n_s, cores)
+        budget = 12.0 if cpu_baseline is True else float(cpu_baseline)       # seconds of wall time per leg
+        quota, hw = cpu_quota()
+        granted = max(1, min(hw, int(round(quota)))) if quota else hw              # the cores this process can actually use
         note = "C++ restatement of the Go path (oracle/), OpenMP across queries; the Go reference is not runnable here (no toolchain)"
-        quota = None
-        try:      # (a container's CPU quota: the threads above share this many cores)
-            q_us, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            quota = None if q_us == "max" else float(q_us) / float(period)
-        except (OSError, ValueError):
-            pass
-        cpu = {"value": n_s / dt, "unit": "queries/s", "cores": used, "cpu_quota_cores": quota, "kind": "port",
-               "sample": "first %d queries of batch 0, same %d-string dictionary; %s" % (n_s, w["dict_size"], note)}
-        n_1 = int(max(16, min(n_s, cpu["value"] / max(used, 1) * budget / 2)))      # ~budget/2 s on one thread
+
+        def leg(threads, n_fixed=None):
+            n = n_fixed
+            if n is None:
+                probe = min(n_q, 2048 if budget >= 8 else 512)
+                _, dt_p = timed(probe, threads)
+                n = int(min(n_q, max(probe, probe / max(dt_p, 1e-6) * budget)))
+            res, dt_l = timed(n, threads)
+            return res, n, dt_l
+
+        n_fix = min(args.cpu_sample or parity_rows or 0, n_q) or None
+        (oi, os_, oc, used), n_s, dt = leg(granted, n_fix)
+        legs = {"granted_cores": {"value": n_s / dt, "unit": "queries/s", "cores": used, "sample": "first %d queries of batch 0" % n_s}}
+        if hw != granted:      # every hardware thread the host shows: oversubscribes the container's quota (kept as a labelled record)
+            n_h = int(max(16, min(n_s, legs["granted_cores"]["value"] * budget / 2)))
+            (_, _, _, used_h), dt_h = timed(n_h, hw)
+            legs["all_hw_threads"] = {"value": n_h / dt_h, "unit": "queries/s", "cores": used_h, "sample": "first %d queries of batch 0" % n_h,
+                                      "note": "threads = every hardware thread of the host; the container's CPU quota is %s cores" % (quota,)}
+        n_1 = int(max(16, min(n_s, legs["granted_cores"]["value"] / max(used, 1) * budget / 2)))      # ~budget/2 s on one thread
         (_, _, _, used1), dt1 = timed(n_1, 1)
-        cpu["one_thread"] = {"value": n_1 / dt1, "unit": "queries/s", "cores": used1, "sample": "first %d queries of batch 0" % n_1}
-        if quota and int(round(quota)) < used:            # as many threads as the container's CPU quota grants cores: not oversubscribed
-            tq = max(1, int(round(quota)))
-            n_q_ = int(max(16, min(n_s, cpu["value"] * budget / 2)))
-            (_, _, _, usedq), dtq = timed(n_q_, tq)
-            cpu["at_quota"] = {"value": n_q_ / dtq, "unit": "queries/s", "cores": usedq, "sample": "first %d queries of batch 0" % n_q_,
-                               "note": "threads = the cgroup CPU quota (the all-threads leg above oversubscribes it)"}
+        legs["one_thread"] = {"value": n_1 / dt1, "unit": "queries/s", "cores": used1, "sample": "first %d queries of batch 0" % n_1}
+        best = max(("granted_cores", "all_hw_threads"), key=lambda n_: legs.get(n_, {"value": -1.0})["value"])
+        cpu = {"value": legs[best]["value"], "unit": "queries/s", "cores": legs[best]["cores"], "cores_granted": granted, "cpu_quota_cores": quota,
+               "hw_threads": hw, "best_leg": best, "kind": "port",
+               "sample": "%s, same %d-string dictionary; %s" % (legs[best]["sample"], w["dict_size"], note)}
+        cpu.update({n_: v for n_, v in legs.items()})
         valid = np.arange(k)[None, :] < np.minimum(oc, k)[:, None]
         same = np.array_equal(cnt[0][:n_s], oc) and np.array_equal(ids[0][:n_s][valid], oi[valid]) and \
             np.array_equal(sc[0][:n_s].view(np.uint64)[valid], os_.view(np.uint64)[valid])
@@ -440,11 +481,11 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         # run; parity is defined against the untightened order.  How many of the checked queries are tie-sensitive (k-th and
         # (k+1)-th best scores bit-equal) says how many rows that caveat can touch at all: the oracle at k + 1 on a subsample.
         n_t = int(min(n_s, 4096))
-        (_, ts_, tc_, _), _ = (ora.suggest_batch(qb[:int(qo[n_t])], qo[:n_t + 1], w["metric"], w["similarity"], k + 1, threads=cores), None)
+        (_, ts_, tc_, _), _ = (ora.suggest_batch(qb[:int(qo[n_t])], qo[:n_t + 1], w["metric"], w["similarity"], k + 1, threads=granted), None)
         tie = int(np.sum((tc_ > k) & (ts_.view(np.uint64)[:, k - 1] == ts_.view(np.uint64)[:, k])))
         parity["tie_sensitive_queries"] = {"count": tie, "of": n_t, "note": "k-th and (k+1)-th best scores bit-equal (SURVEY.md A.6)"}
-        log("[%s] cpu baseline %.0f q/s on %d threads, %.0f q/s on one; GPU result bit-exact vs oracle on the sample: %s"
-            % (w["name"], cpu["value"], used, cpu["one_thread"]["value"], same))
+        log("[%s] cpu baseline %.0f q/s on %d threads (%s; %d cores granted), %.0f q/s on one; GPU result bit-exact vs oracle on %d rows: %s"
+            % (w["name"], cpu["value"], cpu["cores"], best, granted, cpu["one_thread"]["value"], n_s, same))
         del ora
 
     key = "%d/%d/q%d/%s/%.3g/k%d/%s" % (w["dict_size"], n_q, w["ngram"], w["metric"], w["similarity"], k, w["variant"])
@@ -493,8 +534,14 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                         "traffic": d["traffic_bytes_per_call"], "achieved": d_gbps, "frac": d_gbps / HBM_PEAK_GBS, "frac_of_achievable": d_gbps / achievable,
                         "share_of_call_time": d["ms_per_call_under_profiler"] / max(1e-9, sum(v["ms_per_call_under_profiler"] for v in per_kernel.values()))}
     pipe_on = bool(per_kernel and "stream" in per_kernel) if per_kernel else None
+    flat = {}
+    if dominant:       # (flat scalars: a record that keeps only scalar keys still carries the dominant kernel's own fraction)
+        flat = {"dominant_kernel": dominant["kernel"], "dominant_ms": dominant["ms"], "dominant_traffic": dominant["traffic"],
+                "dominant_achieved": dominant["achieved"], "dominant_frac": dominant["frac"], "dominant_frac_of_achievable": dominant["frac_of_achievable"]}
+        for kind, v in (per_kernel or {}).items():
+            flat["%s_ms" % kind] = v["ms_per_call_under_profiler"]
     roof = {"bound": "hbm", "achieved": wire, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wire / HBM_PEAK_GBS if wire else None,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_source": traffic_src, **flat,
             "achievable": achievable, "frac_of_achievable": wire / achievable if wire else None,
             "dominant": dominant, "kernels": per_kernel,
             "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBS,
@@ -502,6 +549,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             "model_bytes": model_bytes, "traffic_over_model": traffic / model_bytes if traffic and model_bytes else None,
             "kernel": ("sg_plan_kernel + sg_stream_kernel + sg_verify_kernel (pipeline.inc)" if pipe_on else "sg_search_kernel_t"), "kernel_ms_avg": avg_ms,
             "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_max": float(np.max(kernel_ms)),
+            "kernel_ms_p50": float(np.median(kernel_ms)), "kernel_ms_p05": float(np.percentile(kernel_ms, 5)), "kernel_ms_p95": float(np.percentile(kernel_ms, 95)),
+            "kernel_ms_stdev": float(np.std(kernel_ms)), "timed_region_s": elapsed,
             "algorithmic_bytes_per_launch": alg_timed, "algorithmic_bytes_per_query": alg_timed / n_q,
             "note": "achieved/frac = measured memory traffic per call (PMC: 128-byte lines fetched past the L2, every kernel of the call) / the call's time "
                     "(HIP events around one sg_suggest_batch_device call, no profiler): the physical fraction of the 8 TB/s HBM peak — an upper bound of the "
@@ -534,7 +583,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "index": {"postings": st["n_postings"], "lists": st["n_lists"], "terms": st["n_terms"], "device_bytes": st["device_bytes"],
                              "build": args.build},
                    "results_per_query": float(np.mean([np.minimum(c, k).mean() for c in cnt])),
-                   "pipeline": {"on": pipe_on if pipe_on is not None else pipe_q > 0, "queries_per_call": pipe_q, "left_to_fused_kernel_per_call": pipe_fb}},
+                   "pipeline": {"on": pipe_on if pipe_on is not None else pipe_q > 0, "queries_per_call": pipe_q, "left_to_fused_kernel_per_call": pipe_fb,
+                                "per_sampled_query": pipe_vol}},
         "roofline": roof,
         "cpu_baseline": cpu,
     }
@@ -657,7 +707,7 @@ def main():
     subs = []
     if args.sub_configs == "auto":
         if env.world == 1 and args.config == "headline" and not args.explicit_workload and args.dict_variant == "uniform":
-            subs = ["cfg3", "cfg4", "skewed", "cfg2", "cfg5"]
+            subs = ["cfg3", "cfg4", "skewed", "families", "cfg2", "words", "cfg5"]
     elif args.sub_configs != "none":
         subs = [s for s in args.sub_configs.split(",") if s]
         if env.world > 1:
@@ -691,13 +741,16 @@ def main():
                                   "predictions_per_query": r5["config"]["predictions_per_query"]}
                 env.log("[cfg5] sub-record done in %.0fs" % (time.time() - t0))
             continue
-        if name == "skewed":    # SURVEY.md 8d's skewed variant of the headline (Zipf symbols: long lists at q = 3)
-            sw = dict(CONFIGS["headline"], name="skewed", variant="skewed")
+        if name in ("skewed", "families"):    # SURVEY.md 8d's variants of the headline: Zipf symbols (long lists at q = 3); families of a base
+            sw = dict(CONFIGS["headline"], name=name, variant=name)      # string + 3 edited copies (several near matches per query: the top-k works)
+        elif name == "words":                 # the reference's own word list, k = 10: real-language lists, dozens of matches per query
+            sw = dict(CONFIGS["cfg2"], dict_size=235887, name="words", variant="words")
         else:
             sw = workload_of(args, name)
-        steps = max(5, min(args.steps, 10)) if name not in ("cfg4", "skewed") else max(3, min(args.steps, 5))
+        heavy = name in ("cfg4", "skewed")
+        steps = max(3, min(args.steps, 5)) if heavy else max(5, min(args.steps, 50))
         r = measure(env, args, sw, steps, 2, cpu_baseline=False if args.no_cpu_baseline else 4.0, host_rate=False,
-                    traffic_mode=args.traffic)
+                    traffic_mode=args.traffic, parity_rows=None if heavy else sw["queries"])
         if r:
             roof = r["roofline"]
             sub_recs[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "queries/s", "steps": r["steps"],
@@ -709,7 +762,10 @@ def main():
                               "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
                               "bit_exact": (r.get("parity_vs_oracle") or {}).get("bit_exact"),
                               "checked_queries": (r.get("parity_vs_oracle") or {}).get("checked_queries"),
-                              "cpu_baseline": r["cpu_baseline"], "results_per_query": r["config"]["results_per_query"]}
+                              "cpu_baseline": r["cpu_baseline"], "results_per_query": r["config"]["results_per_query"],
+                              "pipeline": r["config"]["pipeline"], "kernel_ms_stdev": roof["kernel_ms_stdev"],
+                              "dominant_kernel": roof.get("dominant_kernel"), "dominant_ms": roof.get("dominant_ms"), "dominant_frac": roof.get("dominant_frac"),
+                              "kernels_ms": {kk[:-3]: vv for kk, vv in roof.items() if kk.endswith("_ms") and kk not in ("dominant_ms",) and not kk.startswith("kernel_")}}
             env.log("[%s] sub-record done in %.0fs" % (name, time.time() - t0))
     if env.rank == 0:
         k = w["topk"]

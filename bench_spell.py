@@ -134,19 +134,32 @@ def run(args, env=None):
         oix = oracle.OracleIndex(info["word_list"], ngram_size=sc.description.ngram_size, wrap=sc.description.wrap, pad=sc.description.pad,
                                  alphabet=sc.description.alphabet)
         log("oracle model + index in %.1fs" % (time.time() - t0))
-        cores = os.cpu_count() or 1
+        import bench
+        quota, hw = bench.cpu_quota()
+        granted = max(1, min(hw, int(round(quota)))) if quota else hw       # the cores this process can actually use
         qb, qo = batches[0]
         n_s = args.cpu_sample or min(n_q, 8192)
-        t0 = time.perf_counter()
-        oi, oc = olm.predict_batch(oix, qb[:int(qo[n_s])], qo[:n_s + 1], top_k, sim, threads=cores)
-        dt = time.perf_counter() - t0
+
+        def timed(n, threads):
+            t0 = time.perf_counter()
+            r_ = olm.predict_batch(oix, qb[:int(qo[n])], qo[:n + 1], top_k, sim, threads=threads)
+            return r_, time.perf_counter() - t0
+
+        (oi, oc), dt = timed(n_s, granted)
+        legs = {"granted_cores": {"value": n_s / dt, "unit": "predictions/s", "cores": granted, "sample": "first %d queries of batch 0" % n_s}}
+        if hw != granted:
+            _, dt_h = timed(n_s, hw)
+            legs["all_hw_threads"] = {"value": n_s / dt_h, "unit": "predictions/s", "cores": hw, "sample": "first %d queries of batch 0" % n_s,
+                                      "note": "threads = every hardware thread of the host; the container's CPU quota is %s cores" % (quota,)}
         n_1 = max(64, n_s // 32)
-        t0 = time.perf_counter()
-        olm.predict_batch(oix, qb[:int(qo[n_1])], qo[:n_1 + 1], top_k, sim, threads=1)
-        dt1 = time.perf_counter() - t0
-        cpu = {"value": n_s / dt, "unit": "predictions/s", "cores": cores, "kind": "port",
-               "sample": "first %d queries of batch 0, same model; C++ restatement of pkg/spellchecker + pkg/lm (oracle/), OpenMP across queries" % n_s,
-               "one_thread": {"value": n_1 / dt1, "unit": "predictions/s", "cores": 1, "sample": "first %d queries" % n_1}}
+        _, dt1 = timed(n_1, 1)
+        legs["one_thread"] = {"value": n_1 / dt1, "unit": "predictions/s", "cores": 1, "sample": "first %d queries" % n_1}
+        best = max(("granted_cores", "all_hw_threads"), key=lambda n_: legs.get(n_, {"value": -1.0})["value"])
+        cores = legs[best]["cores"]
+        cpu = {"value": legs[best]["value"], "unit": "predictions/s", "cores": cores, "cores_granted": granted, "cpu_quota_cores": quota, "hw_threads": hw,
+               "best_leg": best, "kind": "port",
+               "sample": "%s, same model; C++ restatement of pkg/spellchecker + pkg/lm (oracle/), OpenMP across queries" % legs[best]["sample"]}
+        cpu.update(legs)
         gi, gc = res
         valid = np.arange(top_k + 1)[None, :] < np.minimum(oc, top_k + 1)[:, None]
         same = bool(np.array_equal(gc[:n_s], oc) and np.array_equal(gi[:n_s][valid], oi[valid]))

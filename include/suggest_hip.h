@@ -315,10 +315,6 @@ int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* ou
  * whose longest term holds max_term_chunks; and the same for a built index together with its two statistics. */
 int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[6]);
 int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[6]);
-/* [r5] the class store (the document side of the prefix filter, csrc/packed_store.inc) checked against the main store and the
- * forward index on the host (small dictionaries): out = {classes, tail ranks per class, chunks, postings, main chunks, main
- * postings, lists that differ, postings in the wrong class}; all zero when the replica has no class store */
-int sg_debug_class_store(sg_index* index, uint64_t out[8]);
 
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
  * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_PRETOK, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */

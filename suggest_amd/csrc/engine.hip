@@ -44,7 +44,6 @@ namespace sg {
 #define SG_PPC 7           // postings per 16-byte chunk of the packed store: {u32 first x, 6 x u16 gaps} (packed_store.inc)
 #define SG_X_MASK 0x1FFFFFFFu   // first word of a chunk: x of its first posting | (postings in the chunk - 1) << 29
 #define SG_PAD_GAP 41u          // gap of the padding slots behind a chunk's last posting (packed_store.inc)
-#define SG_CLS_MAX 8u           // most classes of the class store (packed_store.inc; the plan launch keeps a run per class in registers)
 #define SG_PPC8 13         // ... of a dense term's chunk: {u32 first x, 12 x u8 gaps} (packed_store.inc; the term's format = bit 31 of its seg_off entries)
 #define SG_X_MASK8 0x0FFFFFFFu  // first word of such a chunk: x | (postings in the chunk - 1) << 28
 #define SG_G8_FLAG 0x80000000u
@@ -114,11 +113,6 @@ struct DeviceIndex {
   // candidate is ONE coalesced read of its term list instead of a binary search in every query term's posting list
   const uint2* fwd_rec;        // [n_docs] indexed by x: {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
   const uint32_t* fwd_terms;   // term ids, a doc's list padded to a whole chunk with 0xFFFFFFFF
-  // [r5] the class store (packed_store.inc): the postings once more, lists split by the term's tail rank in the document; null: not built
-  const uint32_t* cls_post;    // chunks, as `postings`
-  const uint32_t* cls_off;     // [(term * cls_n + class) * (S+1) + segment] first chunk
-  const uint32_t* term_rank;   // [n_terms] the global order of terms (ascending volume)
-  uint32_t cls_n, cls_shift;   // class = min(tail rank >> cls_shift, cls_n - 1)
   uint32_t n_dups, n_dup_docs, n_extra;
   uint32_t has_g8;             // some term's lists have 8-bit gaps (bit 31 of its seg_off entries): the launches take the kG8 instantiations
   uint32_t slot_mask, n_na, n_lower;
@@ -412,7 +406,7 @@ __device__ uint32_t d_lm_count(const uint64_t* values, uint32_t from, uint32_t t
 // Tokeniser: wrap -> lower -> trim -> q-grams (first-occurrence dedup) -> normalise -> term ids.
 // Returns the token count A (tokens absent from the dictionary keep their slot as kNoTerm), or -1
 // when the query exceeds SG_MAX_A tokens / SG_MAX_RUNES runes.  Wave-uniform control flow.
-__device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
+__device__ __forceinline__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
                           uint32_t* term, int lane) {
   const DeviceIndex& ix = a.ix;
   const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete == 1 ? 0u : ix.n_wrap1;

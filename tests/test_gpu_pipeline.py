@@ -150,71 +150,6 @@ def test_default_policy():
         assert d == {"unplanned": 0, "overflow": 0, "repeats": 0, "queries": 0 if n_docs == 8000 else 4096}, d
 
 
-# ---- the class store: the document side of the prefix filter (csrc/packed_store.inc; off by default: SG_CLS_N) ----
-@pytest.fixture(scope="module")
-def synth_cls():
-    import os
-    os.environ["SG_CLS_N"] = "8"
-    try:
-        gpu, ora, qb, qo = _pair(60000, 4096, seed=5)
-    finally:
-        del os.environ["SG_CLS_N"]
-    gpu.tune(SG_PIPE=1)
-    return gpu, ora, qb, qo
-
-
-def _class_store(gpu):
-    import ctypes
-    from suggest_amd import _lib
-    out = (ctypes.c_uint64 * 8)()
-    _lib.check(_lib.lib().sg_debug_class_store(gpu._h, out))
-    return list(out)
-
-
-def test_class_store_holds_the_main_stores_postings_by_tail_rank(synth_cls):
-    """every list (term, segment) of the class store, its classes together, is the main store's list; every posting sits in the
-    class of its term's tail rank in the document (forward index x term_rank), ascending inside a class"""
-    gpu = synth_cls[0]
-    n_cls, width, chunks, postings, main_chunks, main_postings, lists_differ, wrong_class = _class_store(gpu)
-    assert (n_cls, width) == (8, 2) and chunks > 0
-    assert postings == main_postings and lists_differ == 0 and wrong_class == 0
-
-
-def test_no_class_store_unless_asked_for(synth_pipe):
-    assert _class_store(synth_pipe[0]) == [0] * 8
-
-
-@pytest.mark.parametrize("metric,alpha,k", [("jaccard", 0.5, 10), ("jaccard", 0.8, 5), ("cosine", 0.4, 20), ("dice", 0.6, 64), ("overlap", 0.7, 10), ("exact", 1.0, 3)])
-def test_parity_through_the_class_store(synth_cls, metric, alpha, k):
-    gpu, ora, qb, qo = synth_cls
-    assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
-    try:
-        gpu.tune(SG_PIPE_CLS=0)                # the same index through the main store
-        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
-    finally:
-        gpu.tune(SG_PIPE_CLS=1)
-
-
-def test_class_store_with_repeated_query_terms_and_a_tabulated_metric():
-    """digits normalise to the pad: queries hold a term twice (the document side of the filter is left out for them) and
-    documents repeat terms; an opaque metric's thresholds need not grow with the segment"""
-    import os
-    os.environ["SG_CLS_N"] = "4"; os.environ["SG_CLS_SHIFT"] = "2"
-    try:
-        gpu, ora, qb, qo = _pair(40000, 4096, desc=dict(alphabet=("english", "$")), seed=13)
-    finally:
-        del os.environ["SG_CLS_N"], os.environ["SG_CLS_SHIFT"]
-    gpu.tune(SG_PIPE=1)
-    assert _class_store(gpu)[:2] == [4, 4]
-    for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.5, 5)):
-        assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
-    tabs = gpu.metric_tables("dice", 0.6, 80)
-    try:
-        assert_same(gpu.suggest_batch(blob=qb, offs=qo, k=10, tables=tabs), ora.suggest_batch(qb, qo, "dice", 0.6, 10))
-    finally:
-        tabs.close()
-
-
 def test_a_batch_above_the_direct_ordering_limit():
     """more than 128 blocks of 1024 queries: the ordering launches keep their batch-wide histogram (atomics + memset) instead of
     summing the blocks' own (engine.hip query_order_*); ordered or not, fused kernel or pipeline, the rows are the oracle's"""

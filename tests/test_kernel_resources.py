@@ -44,18 +44,22 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
         nm = b.split()[0]
         res[nm] = {k: int(v) for k, v in re.findall(r"remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", b)}
     stream = [v for k, v in res.items() if "sg_stream_kernelILi" in k]
-    assert len(stream) == 4, list(res)                                    # 8, 4, 2 wavefronts or 1 (capi.inc tune_choice: by the index's query volume)
+    assert len(stream) == 6, list(res)                                    # 8, 4 or 2 wavefronts (capi.inc tune_choice: by the index's query volume) x 4- / 8-byte sub-row descriptors
     for b in stream:
         assert b["VGPRs"] <= 64 and b["TotalSGPRs"] <= 80 and b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8, b
-    plan = [v for k, v in res.items() if "sg_plan_kernel_t" in k]            # main store / class store
-    assert len(plan) == 2, list(res)
-    for b in plan:                                                         # (5 KB of LDS: 32 wavefronts per CU, if the registers allow 8 per SIMD)
-        assert b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8 and b["VGPRs"] <= 64, b
+    # [r6] the plan and verify launches are persistent wavefronts (a loop over queries): the plan keeps eight wavefronts per SIMD
+    # (5 KB of LDS: 32 per CU) with a handful of spilled dwords at the loop's edges, the verify launch seven
+    plan = [v for k, v in res.items() if "sg_plan_kernel" in k]
+    assert len(plan) == 1, list(res)
+    for b in plan:
+        assert b["ScratchSize [bytes/lane]"] <= 48 and b["Occupancy [waves/SIMD]"] == 8 and b["VGPRs"] <= 64, b
+    verify = [v for k, v in res.items() if "sg_verify_kernel" in k]
+    assert len(verify) == 1 and verify[0]["ScratchSize [bytes/lane]"] == 0 and verify[0]["Occupancy [waves/SIMD]"] >= 7, verify
     # ... and its row loop: a row's seven counter atomics sit in blocks that wait for the row with vmcnt(1) (the next row's load
     # stays in flight), and the wait that ends the loop — vmcnt(0), before the last groups' barriers clear counters out of
     # registers the compiler takes for free — names the row registers
     asm_all = open(tmp_path / "engine.s").read().split("\n")
-    for variant in ("_ZN2sg16sg_stream_kernelILi8E", "_ZN2sg16sg_stream_kernelILi4E", "_ZN2sg16sg_stream_kernelILi2E", "_ZN2sg16sg_stream_kernelILi1E"):
+    for variant in ["_ZN2sg16sg_stream_kernelILi%dELb%dE" % (nw, wide) for nw in (8, 4, 2) for wide in (0, 1)]:
         start = next(i for i, l in enumerate(asm_all) if l.startswith(variant))
         end = next(i for i in range(start, len(asm_all)) if asm_all[i].startswith(".Lfunc_end"))
         body = [l.strip() for l in asm_all[start:end]]

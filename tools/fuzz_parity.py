@@ -66,14 +66,12 @@ def make_trial(seed, scale=1):
     # (round 5, drawn last again) plan -> stream -> verify: forced / by policy / off, every stream workgroup, tiny candidate slots
     # (overflow -> the fused kernel), the class store (the document side of the prefix filter) in several geometries
     env["SG_PIPE"] = rng.choice(["0", "1", "1", "1", "2"])
-    env["SG_PIPE_NW"] = rng.choice(["1", "2", "4", "8"])
+    env["SG_PIPE_NW"] = rng.choice(["2", "4", "8"])
     env["SG_PIPE_LOG2_CNT"] = rng.choice(["9", "10", "11", "12", "13"])
     env["SG_PIPE_DT_BYTES"] = rng.choice(["1024", "2048", "4096", "8192"])
     env["SG_PIPE_SUB"] = rng.choice(["3", "4", "5"])
     env["SG_PIPE_CAND_CAP"] = rng.choice(["2", "16", "64", "64", "512"])
-    env["SG_CLS_N"] = rng.choice(["0", "0", "2", "4", "8"])
-    env["SG_CLS_SHIFT"] = rng.choice(["0", "1", "2"])
-    env["SG_PIPE_CLS"] = rng.choice(["0", "1", "1"])
+    env["SG_PIPE_WIDE"] = rng.choice(["0", "0", "1"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 

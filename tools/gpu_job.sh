@@ -99,6 +99,11 @@ skip = int(sys.argv[1])
 print("plan stage %d verify stage %d: " % ((skip >> 20) & 15, (skip >> 24) & 15) + "  ".join("%s %.1f us (n=%d)" % (k, sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) / 1e3, len(v)) for k, v in sorted(per.items())))
 PY
     done 2>&1 | tee $O/${tag}_plan_stages_${cfg}.txt ;;
+  ab_libs)      # ab_libs <tag> <config> <variant> <lib> [<lib> ...]: [r6] the same workload on several builds of the library (SG_LIB_NAME), twice each, interleaved
+    tag=$1; cfg=$2; var=$3; shift 3
+    for rep in 1 2; do for lib in "$@"; do
+      echo "== $lib (pass $rep)"; SG_LIB_NAME=$lib timeout 900 python tools/pipe_ab.py --config $cfg --variants "$var" --steps 100 2>&1 | grep -v '^\[' | tail -4
+    done; done 2>&1 | tee $O/${tag}_ab_libs_${cfg}.txt ;;
   sh)           # sh <command...>: anything else
     bash -c "$*" ;;
   *) echo "unknown job $job"; exit 2 ;;

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from suggest_amd import IndexDescription, NGramIndex, synth
+from suggest_amd import IndexDescription, NGramIndex, synth, _lib
 import bench
 
 ap = argparse.ArgumentParser()
@@ -35,7 +35,7 @@ d_q = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.view(np.int64)).to
 d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros((n_q, k), dtype=torch.float64, device=dev)
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-NAMES = dict(cls="SG_PIPE_CLS", dt="SG_PIPE_DT_BYTES", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
+NAMES = dict(dt="SG_PIPE_DT_BYTES", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
              level="SG_FILTER_LEVEL", floor="SG_T_FLOOR")
 
 
@@ -68,11 +68,13 @@ for var in args.variants.split(";"):
             a, b = kv.split("=")
             kn[NAMES[a]] = int(b)
     ix.tune(**kn)
-    ps0 = ix.pipe_stats(); ls0 = ix.launch_stats(); pv0 = ix.pipe_volumes()
+    have_pv = hasattr(_lib.lib(), "sg_index_pipe_volumes")      # (an older build of the library under SG_LIB_NAME)
+    ps0 = ix.pipe_stats(); ls0 = ix.launch_stats(); pv0 = ix.pipe_volumes() if have_pv else None
     ms, res = measure(var)
-    ps1 = ix.pipe_stats(); ls1 = ix.launch_stats(); pv1 = ix.pipe_volumes()
-    ns = max(1, pv1["sampled"] - pv0["sampled"])
-    print("   per sampled query: groups %.2f lists %.1f rows %.1f candidates %.2f" % tuple((pv1[k_] - pv0[k_]) / ns for k_ in ("groups", "lists", "rows", "candidates")), flush=True)
+    ps1 = ix.pipe_stats(); ls1 = ix.launch_stats(); pv1 = ix.pipe_volumes() if have_pv else None
+    if have_pv:
+        ns = max(1, pv1["sampled"] - pv0["sampled"])
+        print("   per sampled query: groups %.2f lists %.1f rows %.1f candidates %.2f" % tuple((pv1[k_] - pv0[k_]) / ns for k_ in ("groups", "lists", "rows", "candidates")), flush=True)
     print("   chunks streamed per sampled query: %.0f" % ((ls1["chunks"] - ls0["chunks"]) / max(1, ls1["sampled"] - ls0["sampled"])), flush=True)
     fb = {k_: (ps1[k_] - ps0[k_]) / (args.steps + 2.0) for k_ in ps1}
     same = ref is not None and all(np.array_equal(x, y) for x, y in zip(res, ref))
