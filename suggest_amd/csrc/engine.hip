@@ -406,7 +406,7 @@ __device__ uint32_t d_lm_count(const uint64_t* values, uint32_t from, uint32_t t
 // Tokeniser: wrap -> lower -> trim -> q-grams (first-occurrence dedup) -> normalise -> term ids.
 // Returns the token count A (tokens absent from the dictionary keep their slot as kNoTerm), or -1
 // when the query exceeds SG_MAX_A tokens / SG_MAX_RUNES runes.  Wave-uniform control flow.
-__device__ __forceinline__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
+__device__ int d_tokenize(const BatchArgs& a, const uint8_t* q, uint32_t qlen, uint32_t* runes, uint64_t* keys,
                           uint32_t* term, int lane) {
   const DeviceIndex& ix = a.ix;
   const uint32_t n_w0 = ix.n_wrap0, n_w1 = a.autocomplete == 1 ? 0u : ix.n_wrap1;

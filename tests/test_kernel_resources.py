@@ -47,12 +47,10 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
     assert len(stream) == 6, list(res)                                    # 8, 4 or 2 wavefronts (capi.inc tune_choice: by the index's query volume) x 4- / 8-byte sub-row descriptors
     for b in stream:
         assert b["VGPRs"] <= 64 and b["TotalSGPRs"] <= 80 and b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8, b
-    # [r6] the plan and verify launches are persistent wavefronts (a loop over queries): the plan keeps eight wavefronts per SIMD
-    # (5 KB of LDS: 32 per CU) with a handful of spilled dwords at the loop's edges, the verify launch seven
     plan = [v for k, v in res.items() if "sg_plan_kernel" in k]
     assert len(plan) == 1, list(res)
-    for b in plan:
-        assert b["ScratchSize [bytes/lane]"] <= 48 and b["Occupancy [waves/SIMD]"] == 8 and b["VGPRs"] <= 64, b
+    for b in plan:                                                         # (5 KB of LDS: 32 wavefronts per CU, if the registers allow 8 per SIMD)
+        assert b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8 and b["VGPRs"] <= 64, b
     verify = [v for k, v in res.items() if "sg_verify_kernel" in k]
     assert len(verify) == 1 and verify[0]["ScratchSize [bytes/lane]"] == 0 and verify[0]["Occupancy [waves/SIMD]"] >= 7, verify
     # ... and its row loop: a row's seven counter atomics sit in blocks that wait for the row with vmcnt(1) (the next row's load

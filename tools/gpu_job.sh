@@ -104,6 +104,24 @@ PY
     for rep in 1 2; do for lib in "$@"; do
       echo "== $lib (pass $rep)"; SG_LIB_NAME=$lib timeout 900 python tools/pipe_ab.py --config $cfg --variants "$var" --steps 100 2>&1 | grep -v '^\[' | tail -4
     done; done 2>&1 | tee $O/${tag}_ab_libs_${cfg}.txt ;;
+  wpc_sweep)    # wpc_sweep <tag> <config> <variant>: [r6] wavefronts per CU of the persistent plan / verify launches (0 = a workgroup per query), per-kernel times
+    tag=$1; cfg=$2; var=$3; shift 3
+    cd /tmp
+    for wp in 0 8 16 24 28 32; do for wv in 0 16 28; do
+      rm -rf /tmp/ps_prof
+      SG_PLAN_WPC=$wp SG_VERIFY_WPC=$wv timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ps_prof -- python $R/tools/pipe_ab.py --config $cfg --variants "$var" --steps 10 --no-fused "$@" > /tmp/ps.log 2>&1
+      python - $wp $wv <<'PY'
+import csv, glob, sys
+per = {}
+for p in glob.glob("/tmp/ps_prof/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        n = r["Kernel_Name"]
+        for key in ("sg_plan_kernel", "sg_verify_kernel", "sg_stream_kernel"):
+            if key in n:
+                per.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("plan wpc %s verify wpc %s: " % (sys.argv[1], sys.argv[2]) + "  ".join("%s %.1f us" % (k, sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) / 1e3) for k, v in sorted(per.items())))
+PY
+    done; done 2>&1 | tee $O/${tag}_wpc_sweep_${cfg}.txt ;;
   sh)           # sh <command...>: anything else
     bash -c "$*" ;;
   *) echo "unknown job $job"; exit 2 ;;
