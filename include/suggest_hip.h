@@ -185,7 +185,9 @@ int sg_suggest_batch_from(sg_index* index, const uint8_t* q_utf8, const uint64_t
  * replica stay serialised on one stream), sg_ticket_wait blocks until the rows are in the caller's buffers and frees the
  * ticket.  Up to 8 tickets may be in flight per replica; two are enough to hide PCIe behind the kernel.  Buffers from
  * sg_host_alloc (pinned) are read / written by the DMA engine directly; other buffers are staged through pinned memory
- * (a memcpy at submit, one at wait).  The caller's buffers must stay valid and untouched until the wait returns.  Submit
+ * (a memcpy at submit, one at wait).  ONLY sg_host_alloc blocks count as pinned, and only when the whole range lies inside one:
+ * memory the caller pinned itself (hipHostMalloc, torch pin_memory) is correct but staged like pageable memory — the library
+ * keeps a registry of its own blocks instead of asking the driver about every pointer (tens of microseconds per call).  The caller's buffers must stay valid and untouched until the wait returns.  Submit
  * and wait may be called from different threads. */
 typedef struct sg_ticket sg_ticket;
 int sg_host_alloc(uint64_t bytes, void** out);
@@ -296,7 +298,7 @@ int sg_index_launch_stats(sg_index* index, uint64_t out[4]);
  * Results never depend on which path answered.  Synchronises the device. */
 int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
 
-/* [r6] The pipeline's sampled volumes, cumulative (wrapping at 2^32): out[0] sampled queries the plan expressed (one in 32 of a batch
+/* [r6] The pipeline's sampled volumes, cumulative (wrapping at 2^32): out[0] sampled queries the plan expressed (one in 256 of a batch
  * above 1 024 queries, else every one), [1] their groups of cardinality segments, [2] streamed lists, [3] rows of 64 lanes,
  * [4] candidates pushed for the sampled queries that reached the verify launch, [5..7] 0.  Introspection for bench.py and the
  * tuner's tests; no reference counterpart.  Synchronises the device. */

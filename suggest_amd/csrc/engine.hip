@@ -113,6 +113,8 @@ struct DeviceIndex {
   // candidate is ONE coalesced read of its term list instead of a binary search in every query term's posting list
   const uint2* fwd_rec;        // [n_docs] indexed by x: {first 16-byte chunk of the doc's terms in fwd_terms, cardinality B | distinct terms << 16}
   const uint32_t* fwd_terms;   // term ids, a doc's list padded to a whole chunk with 0xFFFFFFFF
+  const uint32_t* fx_base;     // [S+1] [r6] (dictionaries of <= 63 segments; else null) fwd_terms is in x order at a fixed stride per segment: document
+                               // x of segment B at chunk fx_base[B] + (x - seg_base[B]) * ceil(B / 4) — fwd_rec[x].x says the same
   uint32_t n_dups, n_dup_docs, n_extra;
   uint32_t has_g8;             // some term's lists have 8-bit gaps (bit 31 of its seg_off entries): the launches take the kG8 instantiations
   uint32_t slot_mask, n_na, n_lower;

@@ -111,12 +111,9 @@ BY_NAME = {"jaccard": JaccardMetric, "cosine": CosineMetric, "dice": DiceMetric,
 def resolve(m):
     if isinstance(m, Metric) or all(hasattr(m, f) for f in ("MinY", "MaxY", "Threshold", "Distance")):
         if not hasattr(m, "code"):
-            # a caller's own implementation of the interface: no device twin — it is tabulated (NGramIndex.metric_tables).  Normalised
-            # here so that every caller can read m.code (an object that cannot take attributes is wrapped)
-            try:
-                m.code = None
-            except AttributeError:
-                m = _Duck(m)
+            # a caller's own implementation of the interface: no device twin — it is tabulated (NGramIndex.metric_tables).  Wrapped, so
+            # that every caller can read m.code and the caller's own object is left as it was (round 5 wrote the attribute onto it)
+            m = _Duck(m)
         return m
     if isinstance(m, str):
         # metric names of the HTTP handler, internal/suggest/api/suggest_handler.go:26-34

@@ -57,7 +57,7 @@ def test_rows_do_not_depend_on_the_pipeline_knobs(synth_pipe, knobs):
         gpu.tune(**base)
 
 
-@pytest.mark.parametrize("shape", [(2, 11, 2048), (4, 12, 4096), (1, 10, 1024), (2, 11, 1024), (1, 9, 2048), (8, 13, 32768)])
+@pytest.mark.parametrize("shape", [(2, 11, 2048), (4, 12, 4096), (2, 10, 1024), (2, 11, 1024), (4, 9, 2048), (8, 13, 32768)])
 def test_rows_do_not_depend_on_the_stream_workgroup(synth_pipe, shape):
     """the stream workgroups tune_choice picks for smaller dictionaries (and smaller ones still: more queries go back to the
     fused kernel for want of descriptors)"""
@@ -68,6 +68,50 @@ def test_rows_do_not_depend_on_the_stream_workgroup(synth_pipe, shape):
             assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
     finally:
         gpu.tune(SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_PIPE_DT_BYTES=8192)
+
+
+def test_wide_sub_row_descriptors(synth_pipe):
+    """[r6] stores of 2^26 chunks (1 GiB) and more take 8-byte sub-row descriptors and 64-bit row addresses (pipeline.inc, kWide);
+    SG_PIPE_WIDE forces them on a small store: the rows must not tell, and the queries still take the three launches"""
+    gpu, ora, qb, qo = synth_pipe
+    try:
+        gpu.tune(SG_PIPE_WIDE=1)
+        for nw, cnt, dt in ((8, 13, 8192), (2, 11, 2048), (4, 12, 4096)):
+            gpu.tune(SG_PIPE_NW=nw, SG_PIPE_LOG2_CNT=cnt, SG_PIPE_DT_BYTES=dt)
+            for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20)):
+                res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k))
+                assert_same(res, ora.suggest_batch(qb, qo, metric, alpha, k))
+                assert d["queries"] == 4096 and d["unplanned"] < 410, d
+    finally:
+        gpu.tune(SG_PIPE_WIDE=0, SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_PIPE_DT_BYTES=8192)
+
+
+@pytest.mark.parametrize("k", [65, 100, 500])
+def test_top_k_above_the_lds_rows_takes_the_pipeline(k):
+    """[r6] k > 64: the verify launch keeps its top-k rows in HBM (as the fused kernel does) instead of handing the launch back —
+    near-duplicate families and a low similarity, so that rows really hold more than 64 entries"""
+    gpu, ora, qb, qo = _pair(40000, 2048, seed=9, families=79)
+    gpu.tune(SG_PIPE=1, SG_PIPE_CAND_CAP=4096, SG_TIGHTEN=0)        # (threshold tightening is the fused kernel's: a launch with it on never takes the pipeline)
+    res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=qb, offs=qo, metric="jaccard", similarity=0.2, k=k))
+    want = ora.suggest_batch(qb, qo, "jaccard", 0.2, k)
+    assert_same(res, want)
+    assert d["queries"] == 2048, d
+    assert int(np.minimum(want[2], k).max()) > 64, int(want[2].max())      # (rows that really hold more than the LDS rows' 64 entries)
+
+
+def test_records_beyond_the_head_take_overflow_blocks(synth_pipe):
+    """[r6] a stream record's head holds 16 groups and 174 lists; 2^9 counters and a low similarity make queries of dozens of
+    groups: their tails live in overflow blocks (a pool of n / 8: some queries find it empty and go to the fused kernel)"""
+    gpu, ora, qb, qo = synth_pipe
+    try:
+        gpu.tune(SG_PIPE_LOG2_CNT=9, SG_T_FLOOR=2, SG_FILTER_LEVEL=0)
+        v0 = gpu.pipe_volumes()
+        for metric, alpha, k in (("cosine", 0.3, 10), ("jaccard", 0.3, 5)):
+            assert_same(gpu.suggest_batch(blob=qb, offs=qo, metric=metric, similarity=alpha, k=k), ora.suggest_batch(qb, qo, metric, alpha, k))
+        v1 = gpu.pipe_volumes()
+        assert v1["sampled"] > v0["sampled"] and (v1["groups"] - v0["groups"]) / (v1["sampled"] - v0["sampled"]) > 8, (v0, v1)
+    finally:
+        gpu.tune(SG_PIPE_LOG2_CNT=13, SG_T_FLOOR=8, SG_FILTER_LEVEL=4)
 
 
 def test_candidate_overflow_goes_to_the_fused_kernel(synth_pipe):

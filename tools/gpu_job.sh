@@ -122,6 +122,34 @@ for p in glob.glob("/tmp/ps_prof/**/*kernel_trace.csv", recursive=True):
 print("plan wpc %s verify wpc %s: " % (sys.argv[1], sys.argv[2]) + "  ".join("%s %.1f us" % (k, sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) / 1e3) for k, v in sorted(per.items())))
 PY
     done; done 2>&1 | tee $O/${tag}_wpc_sweep_${cfg}.txt ;;
+  timeline)     # timeline <tag> <config> <variant> <lib>...: [r6] the launches of one call in order, start offsets and durations (kernel trace), per library build
+    tag=$1; cfg=$2; var=$3; shift 3
+    cd /tmp
+    for lib in "$@"; do
+      rm -rf /tmp/tl_prof
+      SG_LIB_NAME=$lib timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_prof -- python $R/tools/pipe_ab.py --config $cfg --variants "$var" --steps 12 --no-fused > /tmp/tl.log 2>&1
+      python - $lib <<'PY'
+import csv, glob, sys
+rows = []
+for p in glob.glob("/tmp/tl_prof/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+# calls = runs of launches that begin with query_order_count
+starts = [i for i, r in enumerate(rows) if "query_order_count" in r[2]]
+calls = [rows[a:b] for a, b in zip(starts, starts[1:] + [len(rows)])]
+calls = [c for c in calls if any("sg_stream_kernel" in r[2] for r in c)][-6:-1]
+print("== %s: %d calls averaged" % (sys.argv[1], len(calls)))
+n = min(len(c) for c in calls)
+for j in range(n):
+    off = sum(c[j][0] - c[0][0] for c in calls) / len(calls) / 1e3
+    dur = sum(c[j][1] - c[j][0] for c in calls) / len(calls) / 1e3
+    gap = sum((c[j][0] - c[j - 1][1]) if j else 0 for c in calls) / len(calls) / 1e3
+    print("  +%8.1f us  gap %6.1f  dur %8.1f  %s" % (off, gap, dur, calls[0][j][2][:70]))
+print("  call span %.1f us; next call starts +%.1f us after this one's first launch" % (sum(c[-1][1] - c[0][0] for c in calls) / len(calls) / 1e3,
+      sum(calls[i + 1][0][0] - calls[i][0][0] for i in range(len(calls) - 1)) / max(1, len(calls) - 1) / 1e3))
+PY
+    done 2>&1 | tee $O/${tag}_timeline_${cfg}.txt ;;
   sh)           # sh <command...>: anything else
     bash -c "$*" ;;
   *) echo "unknown job $job"; exit 2 ;;
