@@ -162,11 +162,17 @@ class Env:
             # its own, made lazily, checked once outside the timed region (config.rccl_gather_check).
             dist.init_process_group("gloo")
             self.nccl_group = None
+            # what became of RCCL in this run, for the line (`config.rccl_status`): a run must not look like an RCCL run when it was not
+            self.rccl_status = "not attempted (SG_BENCH_BACKEND=%s)" % self.backend
             if self.backend == "nccl":
                 try:
                     self.nccl_group = dist.new_group(backend="nccl")
+                    self.rccl_status = "group created"
                 except Exception as exc:
+                    self.rccl_status = "refused at group creation: %r" % (exc,)
                     self.log("no RCCL group (%r): the optional result gather is skipped" % (exc,))
+        else:
+            self.rccl_status = "n/a (one rank)"
 
     def log(self, *a):
         if self.rank == 0:
@@ -283,6 +289,8 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     pv1 = index.pipe_volumes()
     pv_n = (pv1["sampled"] - pv0["sampled"]) % (1 << 32)
     pipe_vol = {k_: ((pv1[k_] - pv0[k_]) % (1 << 32)) / float(pv_n) for k_ in ("groups", "lists", "rows", "candidates")} if pv_n else None
+    if pipe_vol:
+        pipe_vol.update(packed_chunks=pv1["packed_chunks"], wide_descriptors=pv1["wide"])
     pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1 if k_ != "queries"}    # queries per call the pipeline left to the fused kernel
     pipe_q = (ps1.get("queries", 0) - ps0.get("queries", 0)) / float(steps)                              # ... and those it took
     d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)
@@ -315,9 +323,13 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
             gather_ms = float(tg.item())
+            if env.nccl_group is not None:
+                env.rccl_status = "ok: all_gather of the result rows over RCCL, %d ranks" % world
         except Exception as exc:        # the timed region has no collective: report, do not lose the measurement
             log("result gather over RCCL failed: %r" % (exc,))
             gather_ok = False
+            if env.backend == "nccl":
+                env.rccl_status = "refused at the first collective: %s" % (repr(exc)[:300],)
 
     reached = {i % n_b for i in range(warmup)} | {i % n_b for i in range(steps)}
     for b in range(n_b):                                 # (batches the run never reached)
@@ -576,6 +588,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
                    "parallelism": "query-sharded x%d, index replica per GPU, one process per GPU%s"
                                   % (world, ", RCCL all_gather of results in every step" if world > 1 and args.gather else ""),
                    "rccl_gather_check": gather_ok,
+                   "rccl_status": env.rccl_status,      # "ok ..." / "refused ..." (e.g. two ranks on one GPU) / "not attempted (gloo)": never silent
                    "rccl_ranks": rccl_ranks,          # the ranks the RCCL group spans, as all-gathered over it (N > 1)
                    "parity_per_rank": parity_ranks,   # every rank's own rows against the CPU oracle on a sample (N > 1)
                    "gather_ms": gather_ms,       # the optional all_gather of one step's result rows (3 collectives, k*(u32,f64)+u32 per query), max over ranks, untimed region

@@ -300,8 +300,9 @@ int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
 
 /* [r6] The pipeline's sampled volumes, cumulative (wrapping at 2^32): out[0] sampled queries the plan expressed (one in 256 of a batch
  * above 1 024 queries, else every one), [1] their groups of cardinality segments, [2] streamed lists, [3] rows of 64 lanes,
- * [4] candidates pushed for the sampled queries that reached the verify launch, [5..7] 0.  Introspection for bench.py and the
- * tuner's tests; no reference counterpart.  Synchronises the device. */
+ * [4] candidates pushed for the sampled queries that reached the verify launch, [5] 16-byte chunks of the packed posting store,
+ * [6] 1 when the stream launch uses 8-byte sub-row descriptors (stores of 2^26 chunks and more), [7] 0.  Introspection for
+ * bench.py and the tests; no reference counterpart.  Synchronises the device. */
 int sg_index_pipe_volumes(sg_index* index, uint64_t out[8]);
 
 /* The forward index (doc -> distinct terms) of the primary replica, copied back for documents
@@ -317,6 +318,9 @@ int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* ou
  * whose longest term holds max_term_chunks; and the same for a built index together with its two statistics. */
 int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[6]);
 int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[6]);
+/* [r6] Test hook: out[0] = the device ordinal of replica number `replica`, out[1..7] = the device its posting store, seg_off, orig_of,
+ * forward-index records and terms, term table and counter block are resident on (-1: null).  All must equal out[0]. */
+int sg_debug_replica_devices(sg_index* index, uint32_t replica, int32_t out[8]);
 
 /* Sets a tuning knob of the index (names and ranges of the SG_* environment variables in DESIGN.md: SG_LOG2_CNT, SG_T_FLOOR,
  * SG_FILTER_LEVEL, SG_TIGHTEN, SG_ROOMY, SG_ORDER, SG_PRETOK, SG_SPLIT_CHUNKS, SG_PARTS_CNT_BONUS).  Results never depend on the knobs; for parameter sweeps. */

@@ -457,7 +457,8 @@ class NGramIndex:
         out = (C.c_uint64 * 8)()
         with self._use() as h:
             _lib.check(_lib.lib().sg_index_pipe_volumes(h, out))
-        return {"sampled": int(out[0]), "groups": int(out[1]), "lists": int(out[2]), "rows": int(out[3]), "candidates": int(out[4])}
+        return {"sampled": int(out[0]), "groups": int(out[1]), "lists": int(out[2]), "rows": int(out[3]), "candidates": int(out[4]),
+                "packed_chunks": int(out[5]), "wide": bool(out[6])}
 
     def stats(self):
         st = _lib.SgStats()

@@ -87,6 +87,35 @@ def test_cfg3_10m_cosine_k20(big_q3):
     assert np.array_equal(d_sc.cpu().numpy().view(np.uint64), sc.view(np.uint64))
 
 
+def test_pipeline_takes_the_headline_and_k_100(big_q3):
+    """[r6] the default policy sends the headline batch — and the same batch at k = 100, top-k rows in HBM — through plan -> stream ->
+    verify (every query counted by sg_index_pipe_stats, none handed back)"""
+    for k in (10, 100):
+        s0 = big_q3.gpu.pipe_stats()
+        big_q3.check("jaccard", 0.5, k, every=16)
+        s1 = big_q3.gpu.pipe_stats()
+        d = {n: s1[n] - s0[n] for n in s1}
+        assert d["queries"] == N_Q and d["unplanned"] + d["overflow"] + d["repeats"] == 0, (k, d)
+
+
+def test_20m_strings_take_the_pipeline_with_wide_descriptors():
+    """[r6] 20 M strings: a packed store of ~100 M chunks (1.6 GB), above the 2^26 the stream launch's 4-byte sub-row descriptors
+    address — round 5 dropped such an index to the fused kernel without a word.  It now takes the three launches with 8-byte
+    descriptors and 64-bit row addresses; every 16th row of the 65 536-query batch against the oracle, at k = 10 and k = 100."""
+    b = Big(20_000_000, 3)
+    try:
+        pv = b.gpu.pipe_volumes()
+        assert pv["packed_chunks"] >= (1 << 26) and pv["wide"], pv      # the store really is beyond the 4-byte descriptors
+        for k in (10, 100):
+            s0 = b.gpu.pipe_stats()
+            b.check("jaccard", 0.5, k, every=16)
+            s1 = b.gpu.pipe_stats()
+            d = {n: s1[n] - s0[n] for n in s1}
+            assert d["queries"] == N_Q and d["unplanned"] + d["overflow"] < N_Q // 100, (k, d)
+    finally:
+        b.gpu.close(); b.ora.close()
+
+
 def test_cfg4_10m_q2_dice_k10():
     """BASELINE config 4: 10 M strings, q=2 (13 MB of postings per query), Dice >= 0.5, k=10"""
     b = Big(10_000_000, 2)

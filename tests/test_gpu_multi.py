@@ -55,6 +55,17 @@ def test_replicas_and_multi_dispatch(small):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
     with pytest.raises(Exception):
         gpu.suggest_submit(qb, qo, "jaccard", 0.5, 10, *outs[0], replica=3)
+    # [r6] every array of every replica is resident on the replica's own device (hipPointerGetAttributes), and the replicas do not
+    # share arrays: what a cross-device mix-up would look like can be checked without a second GPU
+    import ctypes
+    from suggest_amd import _lib
+    seen = set()
+    for r in range(3):
+        out = (ctypes.c_int32 * 8)()
+        _lib.check(_lib.lib().sg_debug_replica_devices(gpu._h, r, out))
+        assert list(out)[1:] == [out[0]] * 7 and out[0] == gpu.replicas()[r], list(out)
+    out = (ctypes.c_int32 * 8)()
+    assert _lib.lib().sg_debug_replica_devices(gpu._h, 3, out) != 0
 
 
 def test_coalesced_single_query_callers(small):
@@ -197,6 +208,41 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert [x["rank"] for x in pr] == [0, 1] and all(x["checked_queries"] > 0 and x["bit_exact"] is True for x in pr), pr
 
 
+def test_bench_two_ranks_attempt_rccl_and_say_what_happened():
+    """[r6] the same with the `nccl` backend ATTEMPTED: on a box with two GPUs RCCL gathers the rows (`rccl_status` "ok ..."); with both
+    ranks on GPU 0 RCCL refuses (one rank per device) and the line must say so — `rccl_status` "refused ...", `rccl_gather_check`
+    false — instead of quietly measuring over gloo.  Either way the timed region (no collective) and the per-rank parity stand."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", NCCL_DEBUG="WARN")
+    env.pop("SG_BENCH_BACKEND", None)
+    if not two:
+        env["SG_BENCH_SINGLE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dict-size", "200000", "--queries", "4096", "--build", "host"]
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        so, se = proc.communicate(timeout=600)
+    except subprocess.TimeoutExpired:          # (a wedged collective must not outlive the test: the whole process group goes)
+        os.killpg(proc.pid, signal.SIGKILL)
+        so, se = proc.communicate()
+        raise AssertionError("bench.py --gpus 2 (nccl attempted) did not finish: " + so[-1000:] + se[-3000:])
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert lines, so[-2000:] + se[-4000:]            # (the line is printed before the process group is torn down: a teardown error after it is RCCL's, not the measurement's)
+    rec = json.loads(lines[-1])
+    st = rec["config"]["rccl_status"]
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    if two:
+        assert st.startswith("ok") and rec["config"]["rccl_gather_check"] is True, st
+        assert rec["config"]["rccl_ranks"]["ranks"] == [0, 1]
+    else:
+        assert st.startswith("refused") and rec["config"]["rccl_gather_check"] is False, st
+    pr = rec["config"]["parity_per_rank"]
+    assert all(x["checked_queries"] > 0 and x["bit_exact"] is True for x in pr), pr
+
+
 def test_bench_self_spawns_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the way the driver starts the scaling runs) must not measure
     one GPU and call it two: it re-executes itself under torch.distributed.run.  Both ranks on GPU 0, gloo."""
@@ -253,6 +299,23 @@ def test_bench_replicas_mode_single_process():
     # ... and the pinned leg: ONE host thread, a ticket per replica and step (sg_suggest_submit_on), two steps in flight
     piped = rec["replicas_mode"]["pipelined"]
     assert piped["rows_equal_device_run"] is True and piped["value"] > 0
+
+
+def test_replica_arrays_live_on_their_own_devices():
+    """[r6] with two or more GPUs: a replica per device, every array of replica r on device r (sg_debug_replica_devices)"""
+    import ctypes
+    import torch
+    from suggest_amd import _lib, NGramIndex, IndexDescription, synth
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two GPUs")
+    blob, offs = synth.make_dict(20000, seed=3)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**synth.DESCRIPTION))
+    gpu.replicate(list(range(n)))
+    for r, dev in enumerate(gpu.replicas()):
+        out = (ctypes.c_int32 * 8)()
+        _lib.check(_lib.lib().sg_debug_replica_devices(gpu._h, r, out))
+        assert list(out) == [dev] * 8, list(out)
 
 
 def test_multi_dispatch_over_distinct_devices():
