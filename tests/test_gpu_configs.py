@@ -98,11 +98,11 @@ def test_pipeline_takes_the_headline_and_k_100(big_q3):
         assert d["queries"] == N_Q and d["unplanned"] + d["overflow"] + d["repeats"] == 0, (k, d)
 
 
-def test_20m_strings_take_the_pipeline_with_wide_descriptors():
-    """[r6] 20 M strings: a packed store of ~100 M chunks (1.6 GB), above the 2^26 the stream launch's 4-byte sub-row descriptors
+def test_25m_strings_take_the_pipeline_with_wide_descriptors():
+    """[r6] 25 M strings: a packed store of ~72 M chunks (1.15 GB), above the 2^26 the stream launch's 4-byte sub-row descriptors
     address — round 5 dropped such an index to the fused kernel without a word.  It now takes the three launches with 8-byte
     descriptors and 64-bit row addresses; every 16th row of the 65 536-query batch against the oracle, at k = 10 and k = 100."""
-    b = Big(20_000_000, 3)
+    b = Big(25_000_000, 3)
     try:
         pv = b.gpu.pipe_volumes()
         assert pv["packed_chunks"] >= (1 << 26) and pv["wide"], pv      # the store really is beyond the 4-byte descriptors
