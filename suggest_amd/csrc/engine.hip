@@ -2869,6 +2869,7 @@ __global__ __launch_bounds__(64) void pairsort_test_kernel(const uint32_t* keys,
 }
 
 #include "pipeline.inc"
+#include "plan2.inc"
 
 #define sg_search_kernel sg_search_kernel_t<false, false, false, false, false>
 #define sg_search_kernel_loop sg_search_kernel_t<false, false, false, false, false, true>
