@@ -174,6 +174,36 @@ def test_long_and_odd_queries_in_a_pipeline_batch(synth_pipe):
         assert_same(gpu.suggest_batch(blob=b2, offs=o2, metric=metric, similarity=alpha, k=10), ora.suggest_batch(b2, o2, metric, alpha, 10))
 
 
+def test_rows_do_not_depend_on_two_queries_per_plan_wavefront(synth_pipe):
+    """[r6] sg_plan2_kernel (two queries per wavefront, plan2.inc) against sg_plan_kernel (SG_PLAN2=0) and the oracle: ordinary
+    batches over the metrics, an odd number of queries (the last wavefront has one), and a batch where simple queries sit next to
+    ones the half-wavefront path does not take — non-ASCII, more than 32 n-grams, text to trim, empty — in either half"""
+    from suggest_amd import pack_strings
+    gpu, ora, qb, qo = synth_pipe
+    base = [qb[int(qo[i]):int(qo[i + 1])].tobytes() for i in range(2001)]
+    odd = [b"", b"a", b" lead", b"trail ", "naïve été".encode(), b"abcdefghijklmnopqrstuvwxyz0123456789", b"x" * 31, b"y" * 32, b"z" * 33, b"ab", b"abc",
+           b"\xff\xfe abc", b"A1B2C3D4E5F6G7H8"]
+    mixed = []
+    for i, q in enumerate(base[:1500]):
+        mixed.append(q)
+        if i % 7 == 3:
+            mixed.append(odd[(i // 7) % len(odd)])         # (an odd one now in an even slot, now in an odd one)
+    cases = [pack_strings(base), pack_strings(mixed)]
+    try:
+        for two in (1, 0):
+            gpu.tune(SG_PLAN2=two, SG_ORDER=1)
+            for b2, o2 in cases:
+                for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20), ("dice", 0.7, 5), ("overlap", 0.9, 5), ("exact", 1.0, 3)):
+                    res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=b2, offs=o2, metric=metric, similarity=alpha, k=k))
+                    assert_same(res, ora.suggest_batch(b2, o2, metric, alpha, k))
+                    assert d["queries"] == len(o2) - 1, d
+            gpu.tune(SG_ORDER=0)                            # (the batch's own order: pairs of unequal length)
+            b2, o2 = cases[1]
+            assert_same(gpu.suggest_batch(blob=b2, offs=o2, metric="jaccard", similarity=0.5, k=10), ora.suggest_batch(b2, o2, "jaccard", 0.5, 10))
+    finally:
+        gpu.tune(SG_PLAN2=1, SG_ORDER=1)
+
+
 def test_pipeline_with_a_tabulated_metric(synth_pipe):
     """an opaque metric.Metric as host-built tables (pkg/metric/metric.go:7-16) goes through the same three launches"""
     gpu, ora, qb, qo = synth_pipe

@@ -72,6 +72,7 @@ def make_trial(seed, scale=1):
     env["SG_PIPE_SUB"] = rng.choice(["3", "4", "5"])
     env["SG_PIPE_CAND_CAP"] = rng.choice(["2", "16", "64", "64", "512"])
     env["SG_PIPE_WIDE"] = rng.choice(["0", "0", "1"])
+    env["SG_PLAN2"] = rng.choice(["1", "1", "0"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
@@ -138,6 +139,8 @@ def main():
     ap.add_argument("--scale", type=int, default=1, help="multiplies the dictionary sizes (1 .. 20 000 documents)")
     ap.add_argument("--pipe", action="store_true", help="[r5] only trials the plan -> stream -> verify launches are eligible for: dictionaries above 2 048 "
                     "documents, k <= 64, the tokeniser launch on, no tightening / 8-bit gaps / split queries, SG_PIPE=1 (every other knob as drawn)")
+    ap.add_argument("--force", action="append", default=[], help="NAME=VALUE forced onto every trial's knobs (bisecting a mismatch that depends on what ran before it)")
+    ap.add_argument("--first", type=int, default=0, help="the first trial number of the hunt (with --seed: resume a hunt near a mismatch)")
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()
     import torch  # noqa: F401
@@ -150,7 +153,7 @@ def main():
         for m in run_trial(t, verbose=True, only=int(over["only"]) if "only" in over else None, k_override=int(over["k"]) if "k" in over else None):
             print("MISMATCH", m)
         return
-    t_end, trial, bad, piped, piped_trials = time.time() + args.seconds, 0, 0, 0, 0
+    t_end, trial, bad, piped, piped_trials = time.time() + args.seconds, args.first, 0, 0, 0
     while time.time() < t_end:
         seed = args.seed * 100000 + trial
         trial += 1
@@ -163,6 +166,7 @@ def main():
                 continue
             t["env"].update(SG_PIPE="1", SG_PRETOK="1", SG_TIGHTEN="0", SG_G8="0", SG_SPLIT_CHUNKS="0", SG_LOG2_CNT="9")
             t["searches"] = [(m_, a_, min(k_, 64)) for m_, a_, k_ in t["searches"]]
+        t["env"].update(dict(x.split("=") for x in args.force))
         for m in run_trial(t):
             bad += 1
             print("MISMATCH seed %d: %s env=%s build=%s: %s" % (seed, t["desc"], t["env"], t["build"], m), flush=True)
