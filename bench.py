@@ -835,7 +835,7 @@ def main_replicas(env, args, w):
     print(json.dumps(out), flush=True)
 
 
-SEARCH_KERNELS = (("stream", "sg_stream_kernel"), ("plan", "sg_plan_kernel"), ("verify", "sg_verify_kernel"), ("fused", "sg_search_kernel_t<false, false,"),
+SEARCH_KERNELS = (("stream", "sg_stream_kernel"), ("plan", "sg_plan"), ("verify", "sg_verify_kernel"), ("fused", "sg_search_kernel_t<false, false,"),
                   ("parts", "sg_search_kernel_t<true, false,"), ("tokenise", "sg_terms_kernel"), ("order", "query_order_"), ("long", "sg_long_kernel"))
 
 

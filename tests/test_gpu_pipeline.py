@@ -191,7 +191,7 @@ def test_rows_do_not_depend_on_two_queries_per_plan_wavefront(synth_pipe):
     cases = [pack_strings(base), pack_strings(mixed)]
     try:
         for two in (1, 0):
-            gpu.tune(SG_PLAN2=two, SG_ORDER=1)
+            gpu.tune(SG_PLAN2=two, SG_ORDER=1, SG_PRETOK=1)     # (SG_PRETOK: batches of a few thousand queries take the three launches too)
             for b2, o2 in cases:
                 for metric, alpha, k in (("jaccard", 0.5, 10), ("cosine", 0.4, 20), ("dice", 0.7, 5), ("overlap", 0.9, 5), ("exact", 1.0, 3)):
                     res, d = _delta(gpu, lambda: gpu.suggest_batch(blob=b2, offs=o2, metric=metric, similarity=alpha, k=k))
@@ -201,7 +201,7 @@ def test_rows_do_not_depend_on_two_queries_per_plan_wavefront(synth_pipe):
             b2, o2 = cases[1]
             assert_same(gpu.suggest_batch(blob=b2, offs=o2, metric="jaccard", similarity=0.5, k=10), ora.suggest_batch(b2, o2, "jaccard", 0.5, 10))
     finally:
-        gpu.tune(SG_PLAN2=1, SG_ORDER=1)
+        gpu.tune(SG_PLAN2=1, SG_ORDER=1, SG_PRETOK=2048)
 
 
 def test_pipeline_with_a_tabulated_metric(synth_pipe):

@@ -51,6 +51,8 @@ def test_search_kernel_registers_and_stream_loop_schedule(tmp_path):
     assert len(plan) == 1, list(res)
     for b in plan:                                                         # (5 KB of LDS: 32 wavefronts per CU, if the registers allow 8 per SIMD)
         assert b["ScratchSize [bytes/lane]"] == 0 and b["Occupancy [waves/SIMD]"] == 8 and b["VGPRs"] <= 64, b
+    plan2 = [v for k, v in res.items() if "sg_plan2_kernel" in k]          # [r6] two queries per wavefront: eight wavefronts per SIMD, nothing in scratch
+    assert len(plan2) == 1 and plan2[0]["ScratchSize [bytes/lane]"] == 0 and plan2[0]["Occupancy [waves/SIMD]"] == 8 and plan2[0]["VGPRs"] <= 64, plan2
     verify = [v for k, v in res.items() if "sg_verify_kernel_t" in k]       # top-k rows in LDS / in HBM
     assert len(verify) == 2, list(res)
     for b in verify:
