@@ -290,7 +290,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     pv_n = (pv1["sampled"] - pv0["sampled"]) % (1 << 32)
     pipe_vol = {k_: ((pv1[k_] - pv0[k_]) % (1 << 32)) / float(pv_n) for k_ in ("groups", "lists", "rows", "candidates")} if pv_n else None
     if pipe_vol:
-        pipe_vol.update(packed_chunks=pv1["packed_chunks"], wide_descriptors=pv1["wide"])
+        pipe_vol.update(packed_chunks=pv1["packed_chunks"], wide_descriptors=pv1["wide"], stream_workgroup=pv1.get("stream_shape"))
     pipe_fb = {k_: ((ps1[k_] - ps0[k_]) % (1 << 32)) / float(steps) for k_ in ps1 if k_ != "queries"}    # queries per call the pipeline left to the fused kernel
     pipe_q = (ps1.get("queries", 0) - ps0.get("queries", 0)) / float(steps)                              # ... and those it took
     d_s, d_c = (ls1["sampled"] - ls0["sampled"]) % (1 << 32), (ls1["chunks"] - ls0["chunks"]) % (1 << 64)

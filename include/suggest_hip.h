@@ -301,8 +301,10 @@ int sg_index_pipe_stats(sg_index* index, uint64_t out[4]);
 /* [r6] The pipeline's sampled volumes, cumulative (wrapping at 2^32): out[0] sampled queries the plan expressed (one in 256 of a batch
  * above 1 024 queries, else every one), [1] their groups of cardinality segments, [2] streamed lists, [3] rows of 64 lanes,
  * [4] candidates pushed for the sampled queries that reached the verify launch, [5] 16-byte chunks of the packed posting store,
- * [6] 1 when the stream launch uses 8-byte sub-row descriptors (stores of 2^26 chunks and more), [7] 0.  Introspection for
- * bench.py and the tests; no reference counterpart.  Synchronises the device. */
+ * [6] 1 when the stream launch uses 8-byte sub-row descriptors (stores of 2^26 chunks and more), [7] the stream workgroup of the replica's latest
+ * launch: 0 / 1 / 2 = 2 / 4 / 8 wavefronts on 2^11 / 2^12 / 2^13 counters (chosen per launch from the index's expected query volume
+ * and the metric's threshold), 3 = fixed by SG_PIPE_NW / SG_PIPE_LOG2_CNT / SG_PIPE_DT_BYTES.  Introspection for bench.py and the
+ * tests; no reference counterpart.  Synchronises the device. */
 int sg_index_pipe_volumes(sg_index* index, uint64_t out[8]);
 
 /* The forward index (doc -> distinct terms) of the primary replica, copied back for documents

@@ -453,12 +453,13 @@ class NGramIndex:
         return {"unplanned": int(out[0]), "overflow": int(out[1]), "repeats": int(out[2]), "queries": int(out[3])}
 
     def pipe_volumes(self):
-        """the pipeline's sampled volumes (cumulative): {sampled, groups, lists, rows, candidates} — sg_index_pipe_volumes"""
+        """the pipeline's sampled volumes (cumulative): {sampled, groups, lists, rows, candidates} + the store's chunks, descriptor width and the stream workgroup of the latest launch — sg_index_pipe_volumes"""
         out = (C.c_uint64 * 8)()
         with self._use() as h:
             _lib.check(_lib.lib().sg_index_pipe_volumes(h, out))
         return {"sampled": int(out[0]), "groups": int(out[1]), "lists": int(out[2]), "rows": int(out[3]), "candidates": int(out[4]),
-                "packed_chunks": int(out[5]), "wide": bool(out[6])}
+                "packed_chunks": int(out[5]), "wide": bool(out[6]),
+                "stream_shape": ("2 wavefronts x 2^11 counters", "4 x 2^12", "8 x 2^13", "fixed by knobs")[min(int(out[7]), 3)]}
 
     def stats(self):
         st = _lib.SgStats()

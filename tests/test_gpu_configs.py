@@ -96,6 +96,30 @@ def test_pipeline_takes_the_headline_and_k_100(big_q3):
         s1 = big_q3.gpu.pipe_stats()
         d = {n: s1[n] - s0[n] for n in s1}
         assert d["queries"] == N_Q and d["unplanned"] + d["overflow"] + d["repeats"] == 0, (k, d)
+        assert big_q3.gpu.pipe_volumes()["stream_shape"] == "4 x 2^12", big_q3.gpu.pipe_volumes()
+
+
+def test_stream_workgroup_follows_the_launch_not_only_the_index(big_q3):
+    """[r6] the stream workgroup is chosen per launch: on the same 10 M-string index a Jaccard >= 0.5 batch (two thirds of a query's
+    lists left after skipping) streams with four wavefronts on 2^12 counters, a Cosine >= 0.4 batch (nothing skipped) with eight on
+    2^13 — where the lighter shape would leave 40 % of the queries unplanned (profiles/r06final_shape_by_size.txt); none is here.
+    Knobs fix the shape for every launch; SG_PIPE_SHAPE_AUTO gives it back."""
+    gpu = big_q3.gpu
+    s0 = gpu.pipe_stats()
+    big_q3.check("cosine", 0.4, 20, every=64)
+    s1 = gpu.pipe_stats()
+    assert gpu.pipe_volumes()["stream_shape"] == "8 x 2^13", gpu.pipe_volumes()
+    assert s1["queries"] - s0["queries"] == N_Q and s1["unplanned"] == s0["unplanned"], (s0, s1)
+    big_q3.check("jaccard", 0.5, 10, every=64)
+    assert gpu.pipe_volumes()["stream_shape"] == "4 x 2^12", gpu.pipe_volumes()
+    gpu.tune(SG_PIPE_NW=8, SG_PIPE_LOG2_CNT=13, SG_PIPE_DT_BYTES=8192)
+    try:
+        big_q3.check("jaccard", 0.5, 10, every=64)
+        assert gpu.pipe_volumes()["stream_shape"] == "fixed by knobs"
+    finally:
+        gpu.tune(SG_PIPE_SHAPE_AUTO=1)
+    big_q3.check("jaccard", 0.5, 10, every=64)
+    assert gpu.pipe_volumes()["stream_shape"] == "4 x 2^12"
 
 
 def test_25m_strings_take_the_pipeline_with_wide_descriptors():

@@ -36,7 +36,7 @@ d_ids = torch.zeros((n_q, k), dtype=torch.int32, device=dev); d_sc = torch.zeros
 d_cnt = torch.zeros(n_q, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 NAMES = dict(dt="SG_PIPE_DT_BYTES", nw="SG_PIPE_NW", order="SG_ORDER", sub="SG_PIPE_SUB", cnt="SG_PIPE_LOG2_CNT", ccap="SG_PIPE_CAND_CAP",
-             level="SG_FILTER_LEVEL", floor="SG_T_FLOOR")
+             level="SG_FILTER_LEVEL", floor="SG_T_FLOOR", auto="SG_PIPE_SHAPE_AUTO")
 
 
 def run():
@@ -74,7 +74,7 @@ for var in args.variants.split(";"):
     ps1 = ix.pipe_stats(); ls1 = ix.launch_stats(); pv1 = ix.pipe_volumes() if have_pv else None
     if have_pv:
         ns = max(1, pv1["sampled"] - pv0["sampled"])
-        print("   per sampled query: groups %.2f lists %.1f rows %.1f candidates %.2f" % tuple((pv1[k_] - pv0[k_]) / ns for k_ in ("groups", "lists", "rows", "candidates")), flush=True)
+        print("   per sampled query: groups %.2f lists %.1f rows %.1f candidates %.2f  (stream workgroup: %s)" % (tuple((pv1[k_] - pv0[k_]) / ns for k_ in ("groups", "lists", "rows", "candidates")) + (pv1.get("stream_shape"),)), flush=True)
     print("   chunks streamed per sampled query: %.0f" % ((ls1["chunks"] - ls0["chunks"]) / max(1, ls1["sampled"] - ls0["sampled"])), flush=True)
     fb = {k_: (ps1[k_] - ps0[k_]) / (args.steps + 2.0) for k_ in ps1}
     same = ref is not None and all(np.array_equal(x, y) for x, y in zip(res, ref))
