@@ -73,6 +73,8 @@ def make_trial(seed, scale=1):
     env["SG_PIPE_CAND_CAP"] = rng.choice(["2", "16", "64", "64", "512"])
     env["SG_PIPE_WIDE"] = rng.choice(["0", "0", "1"])
     env["SG_PLAN2"] = rng.choice(["1", "1", "0"])
+    # (round 6, drawn last again) no shape knobs: the stream workgroup is chosen per launch (capi.inc, "shape, per launch")
+    env["FUZZ_SHAPE_AUTO"] = rng.choice(["0", "0", "1"])
     return dict(desc=desc, docs=docs, queries=queries, env=env, build=build, searches=searches, limit=limit, syms=syms)
 
 
@@ -81,6 +83,8 @@ def run_trial(t, verbose=False, only=None, k_override=None):
     import oracle
     from suggest_amd import IndexDescription, NGramIndex
     os.environ.update(t["env"])
+    if t["env"].get("FUZZ_SHAPE_AUTO") == "1":
+        for name in ("SG_PIPE_NW", "SG_PIPE_LOG2_CNT", "SG_PIPE_DT_BYTES"): os.environ.pop(name, None)
     tm = t.setdefault("timing", {"gpu": 0.0, "oracle": 0.0})
     t0 = time.time()
     try:
