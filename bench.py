@@ -86,6 +86,7 @@ def parse_args(argv=None):
                     help="index build: on the GPU (sg_index_build_device, 0.4 s at 10M; the posting store stays where it was "
                          "built) or on the host (sg_index_build, then uploaded); same arrays either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-rate", action="store_true", help="skip the host-buffer legs (the profiler child passes: every call of the run is then a device-resident one)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = auto)")
     ap.add_argument("--sub-configs", default="auto",
                     help="comma list of configs measured after the main one and reported under `configs`: BASELINE's cfg2..cfg5, and the "
@@ -536,9 +537,10 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         achievable = float([x for x in mb["segments"] if x["seg_bytes"] == 1024][0]["lines_GBps_1GiB"])
     except (OSError, ValueError, KeyError, IndexError):
         achievable = 6290.0              # (the guide's copy ceiling)
-    dominant = None
+    dominant, kernel_timing = None, None
     if per_kernel:
         dk = per_kernel.pop("_dominant")
+        kernel_timing = per_kernel.pop("_timing", "the counter pass: mean of the later half of each kernel's dispatches (counter collection does not lengthen them: profiles/r06end2_*)")
         d = per_kernel[dk]
         if d["ms_per_call_under_profiler"] > 0:
             d_gbps = d["traffic_bytes_per_call"] / (d["ms_per_call_under_profiler"] * 1e-3) / 1e9
@@ -555,7 +557,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
     roof = {"bound": "hbm", "achieved": wire, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wire / HBM_PEAK_GBS if wire else None,
             "traffic": traffic, "traffic_source": traffic_src, **flat,
             "achievable": achievable, "frac_of_achievable": wire / achievable if wire else None,
-            "dominant": dominant, "kernels": per_kernel,
+            "dominant": dominant, "kernels": per_kernel, "kernels_timed_under": kernel_timing,
             "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBS,
             "traffic_over_algorithmic": traffic / alg_timed if traffic else None,
             "model_bytes": model_bytes, "traffic_over_model": traffic / model_bytes if traffic and model_bytes else None,
@@ -726,7 +728,7 @@ def main():
         if env.world > 1:
             raise SystemExit("--sub-configs is an N=1 option")
     rec = measure(env, args, w, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline, traffic_mode=args.traffic,
-                  replicas_leg=env.world > 1)
+                  replicas_leg=env.world > 1, host_rate=not args.no_host_rate)
     sub_recs = {}
     for name in subs:       # cfg3 and cfg4 first: they share the headline's dictionary
         t0 = time.time()
@@ -861,30 +863,46 @@ def _live_traffic(args, w, log):
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not rocprof:
         return None, "rocprofv3 not found", None
-    tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
-    steps, warm = (4, 2) if w["name"] not in ("cfg4", "skewed") else (2, 1)
-    cmd = [rocprof, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
-           os.path.abspath(__file__), "--config", w["name"] if w["name"] in CONFIGS else "headline", "--dict-size", str(w["dict_size"]), "--queries", str(w["queries"]),
-           "--ngram", str(w["ngram"]), "--metric", w["metric"], "--similarity", repr(w["similarity"]), "--topk", str(w["topk"]),
-           "--batches", str(args.batches), "--dict-variant", w["variant"], "--build", args.build,
-           "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none", "--sub-configs", "none"]
-    t0 = time.time()
-    try:
+    steps, warm = (60, 10) if w["name"] not in ("cfg4", "skewed") else (2, 1)      # (light workloads: long enough for the clocks to settle, as in the timed region)
+    tmps = []
+
+    def child(flags):
+        """this script as a child under rocprofv3 with `flags` -> (KB fetched, ns, dispatches) per kind of kernel"""
+        tmp = tempfile.mkdtemp(prefix="sg_pmc_", dir="/tmp")
+        tmps.append(tmp)
+        cmd = [rocprof] + flags + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+               os.path.abspath(__file__), "--config", w["name"] if w["name"] in CONFIGS else "headline", "--dict-size", str(w["dict_size"]), "--queries", str(w["queries"]),
+               "--ngram", str(w["ngram"]), "--metric", w["metric"], "--similarity", repr(w["similarity"]), "--topk", str(w["topk"]),
+               "--batches", str(args.batches), "--dict-variant", w["variant"], "--build", args.build,
+               "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-host-rate", "--traffic", "none", "--sub-configs", "none"]
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
         if r.returncode != 0:
-            return None, "rocprofv3 child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:]), None
-        kb, ns, n = {}, {}, {}
+            raise ValueError("rocprofv3 child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+        kb, ns, n, nt = {}, {}, {}, {}
         for path in sorted(glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)):
             for row in csv.DictReader(open(path)):
                 kind = _kernel_kind(row.get("Kernel_Name", ""))
                 if kind and row.get("Counter_Name") == "FETCH_SIZE":
                     kb[kind] = kb.get(kind, 0.0) + float(row["Counter_Value"])
                     n[kind] = n.get(kind, 0) + 1
+        spans = {}
         for path in sorted(glob.glob(tmp + "/**/*kernel_trace.csv", recursive=True)):
             for row in csv.DictReader(open(path)):
                 kind = _kernel_kind(row.get("Kernel_Name", ""))
                 if kind:
-                    ns[kind] = ns.get(kind, 0.0) + float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    spans.setdefault(kind, []).append((float(row["Start_Timestamp"]), float(row["End_Timestamp"]) - float(row["Start_Timestamp"])))
+        # durations: the later half of a kind's dispatches, in time order — the run's first calls (cold pages and TLBs, clocks still
+        # rising, the parity pass's other batch sizes) are not what the timed region launches; ns = that mean x all dispatches
+        for kind, v in spans.items():
+            v.sort()
+            late = [d for _, d in v[len(v) // 2:]]
+            ns[kind] = sum(late) / len(late) * len(v)
+            nt[kind] = len(v)
+        return kb, ns, n, nt
+
+    t0 = time.time()
+    try:
+        kb, ns, n, _ = child(["--pmc", "FETCH_SIZE"])
         # the kernel that carries the call: by time (a replica whose pipeline queries mostly come back — near-duplicate families — takes
         # the three launches for a few calls and the fused kernel for the next 64: both show up in one pass)
         main = max(("stream", "fused"), key=lambda kk: ns.get(kk, 0.0)) if (n.get("stream") or n.get("fused")) else None
@@ -904,7 +922,7 @@ def _live_traffic(args, w, log):
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
         return None, "live PMC pass failed: %r" % (exc,), None
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        for tmp in tmps: shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _human(n):
