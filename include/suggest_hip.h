@@ -319,6 +319,10 @@ int sg_debug_pairsort(int device, const uint32_t* keys, uint32_t n, uint32_t* ou
  * verify pipeline pays} for an index whose queries are expected to stream est_query_chunks 16-byte chunks of u32 postings and
  * whose longest term holds max_term_chunks; and the same for a built index together with its two statistics. */
 int sg_debug_tune_choice(double est_query_chunks, double max_term_chunks, int32_t out[6]);
+/* [r6] Test hook: the stream workgroup a launch under `metric` / `similarity` starts from on an index with these statistics
+ * (expected query volume in 16-byte chunks, n-grams per document, SG_T_FLOOR): *out_shape = 0 / 1 / 2 for 2 / 4 / 8 wavefronts on
+ * 2^11 / 2^12 / 2^13 counters.  No GPU needed; no reference counterpart. */
+int sg_debug_pipe_shape(double est_query_chunks, double terms_per_doc, int32_t t_floor, int32_t metric, double similarity, int32_t* out_shape);
 int sg_debug_tune_index(sg_index* index, double out_stats[2], int32_t out[6]);
 /* [r6] Test hook: out[0] = the device ordinal of replica number `replica`, out[1..7] = the device its posting store, seg_off, orig_of,
  * forward-index records and terms, term table and counter block are resident on (-1: null).  All must equal out[0]. */

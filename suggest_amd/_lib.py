@@ -23,7 +23,7 @@ EXPORTS = [
     "sg_lm_load_google", "sg_lm_build_google", "sg_lm_retain", "sg_lm_release", "sg_lm_num_words", "sg_lm_word", "sg_lm_word_id", "sg_lm_score",
     "sg_lm_score_word_ids", "sg_lm_next_score", "sg_lm_tokenize", "sg_spell_index_build", "sg_spell_predict_batch", "sg_spell_predict_batch_device",
     "sg_index_replicate", "sg_index_replicas", "sg_suggest_batch_multi", "sg_autocomplete_batch_multi", "sg_suggest_one", "sg_autocomplete_one", "sg_autocomplete_one_from", "sg_autocomplete_batch_from",
-    "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort", "sg_debug_tune_choice", "sg_debug_tune_index", "sg_debug_replica_devices",
+    "sg_lm_load_google_ex", "sg_lm_load_binary", "sg_lm_level", "sg_lm_order", "sg_index_tune", "sg_index_forward", "sg_autocomplete_algorithmic_bytes", "sg_debug_pairsort", "sg_debug_tune_choice", "sg_debug_pipe_shape", "sg_debug_tune_index", "sg_debug_replica_devices",
     "sg_host_alloc", "sg_host_free", "sg_suggest_submit", "sg_suggest_submit_on", "sg_autocomplete_submit", "sg_ticket_wait",
     "sg_metric_tables_create", "sg_metric_tables_retain", "sg_metric_tables_release", "sg_suggest_batch_tables", "sg_suggest_batch_from", "sg_index_launch_stats", "sg_index_pipe_stats", "sg_index_pipe_volumes",
 ]
@@ -68,6 +68,7 @@ def lib():
     if hasattr(L, "sg_index_tune"): L.sg_index_tune.argtypes = [vp, C.c_char_p, i32]
     if hasattr(L, "sg_debug_pairsort"): L.sg_debug_pairsort.argtypes = [i32, vp, u32, vp]
     if hasattr(L, "sg_debug_tune_choice"): L.sg_debug_tune_choice.argtypes = [dbl, dbl, vp]
+    if hasattr(L, "sg_debug_pipe_shape"): L.sg_debug_pipe_shape.argtypes = [dbl, dbl, i32, i32, dbl, vp]
     if hasattr(L, "sg_debug_tune_index"): L.sg_debug_tune_index.argtypes = [vp, vp, vp]
     if hasattr(L, "sg_debug_replica_devices"): L.sg_debug_replica_devices.argtypes = [vp, u32, vp]
     if hasattr(L, "sg_autocomplete_algorithmic_bytes"): L.sg_autocomplete_algorithmic_bytes.argtypes = [vp, vp, vp, u32, u32, C.POINTER(u64)]

@@ -167,6 +167,35 @@ def test_cdb_dictionary_matches_the_source_lines(cars_lines, golden_dir):
     assert read_cdb_dictionary(os.path.join(golden_dir, "db", "cars.cdb")) == cars_lines
 
 
+def test_stream_shapes_are_pinned():
+    """[r6] The stream workgroup a launch starts from (capi.inc pipe_shape_model) for the sixteen launches it was measured on —
+    1 M ... 16 M synthetic strings (q = 3, 19.99 n-grams per document, SG_T_FLOOR 8) under Jaccard >= 0.5 and Cosine >= 0.4, each
+    with the three shapes side by side on one resident index (profiles/r06final_shape_by_size.txt,
+    r06final_shape_auto_by_size.txt) — and the 25 M-string index of the wide-descriptor test.  0 / 1 / 2 = 2 / 4 / 8 wavefronts on
+    2^11 / 2^12 / 2^13 counters; the expected query volumes are the ones the GPU box printed (SG_VERBOSE)."""
+    import ctypes as C
+    from suggest_amd import _lib
+    L = _lib.lib()
+    JACCARD, COSINE = 0, 1
+
+    def shape(est, metric, alpha, terms=19.99, floor=8):
+        out = C.c_int32(-1)
+        _lib.check(L.sg_debug_pipe_shape(float(est), float(terms), floor, metric, float(alpha), C.byref(out)))
+        return out.value
+
+    est = {1: 2316, 2: 4448, 4: 8711, 6: 12975, 8: 17240, 10: 21500, 13: 27950, 16: 34299, 25: 53484}    # million strings -> chunks
+    fastest = {   # (million strings, metric): the shape with the shortest call in the sweeps
+        (1, JACCARD): 0, (2, JACCARD): 0, (4, JACCARD): 1, (6, JACCARD): 1, (8, JACCARD): 1, (10, JACCARD): 1, (13, JACCARD): 2, (16, JACCARD): 2,
+        (25, JACCARD): 2,
+        (1, COSINE): 0, (2, COSINE): 1, (4, COSINE): 1, (6, COSINE): 2, (8, COSINE): 2, (10, COSINE): 2, (13, COSINE): 2, (16, COSINE): 2,
+    }
+    for (m, metric), want in fastest.items():
+        assert shape(est[m], metric, 0.5 if metric == JACCARD else 0.4) == want, (m, metric)
+    # a similarity that skips nothing streams every list: the heavier shape earlier; a high one the lighter shape later
+    assert shape(est[10], JACCARD, 0.2) == 2 and shape(est[16], JACCARD, 0.8) == 1
+    assert L.sg_debug_pipe_shape(1000.0, 20.0, 8, 7, 0.5, C.byref(C.c_int32())) != 0       # (a tabulated metric has no model: the index's own choice)
+
+
 def test_tuner_choices_are_pinned(cars_lines, words_lines):
     """[r5] The auto-tuner's choices (counter words, filter table, pipeline) for the dictionaries they were measured on — rounds 2-3
     shipped the wrong filter table for three regimes unnoticed.  The statistics of the large synthetic dictionaries are the ones
