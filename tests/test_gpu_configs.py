@@ -122,6 +122,32 @@ def test_stream_workgroup_follows_the_launch_not_only_the_index(big_q3):
     assert gpu.pipe_volumes()["stream_shape"] == "4 x 2^12"
 
 
+def test_a_launch_that_starts_too_light_moves_to_the_heavier_stream_workgroup():
+    """[r6] the counters behind the per-launch choice: 4 M strings under Cosine >= 0.4 want 4 wavefronts on 2^12 counters; started one
+    shape too light (test hook SG_PIPE_SHAPE_BIAS) a quarter of the queries come back unplanned (profiles/r06final_shape_by_size.txt:
+    15 665 of 65 536) — the replica sees it in its counters and takes the next shape from then on; rows equal the fused kernel's on
+    every call.  (Calls through the host-buffer entry point: each one has drained before the next looks at the counters.)"""
+    from suggest_amd import NGramIndex, IndexDescription, synth
+    blob, offs = synth.make_dict(4_000_000, seed=1)
+    qb, qo = synth.make_queries(N_Q, blob, offs, seed=2)
+    gpu = NGramIndex(blob=blob, offs=offs, description=IndexDescription(**dict(synth.DESCRIPTION, ngram_size=3)), build="device")
+    try:
+        gpu.tune(SG_PIPE=0)
+        want = gpu.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.4, k=20)
+        gpu.tune(SG_PIPE=1, SG_PIPE_SHAPE_BIAS=-1)
+        seen, unplanned = [], []
+        for _ in range(16):
+            s0 = gpu.pipe_stats()
+            got = gpu.suggest_batch(blob=qb, offs=qo, metric="cosine", similarity=0.4, k=20)
+            s1 = gpu.pipe_stats()
+            assert all(np.array_equal(x, y) for x, y in zip(got, want))
+            seen.append(gpu.pipe_volumes()["stream_shape"]); unplanned.append(s1["unplanned"] - s0["unplanned"])
+        assert seen[0] == "2 wavefronts x 2^11 counters" and unplanned[0] > N_Q // 100, (seen, unplanned)
+        assert seen[-1] == "4 x 2^12" and unplanned[-1] == 0, (seen, unplanned)
+    finally:
+        gpu.close()
+
+
 def test_25m_strings_take_the_pipeline_with_wide_descriptors():
     """[r6] 25 M strings: a packed store of ~72 M chunks (1.15 GB), above the 2^26 the stream launch's 4-byte sub-row descriptors
     address — round 5 dropped such an index to the fused kernel without a word.  It now takes the three launches with 8-byte
