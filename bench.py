@@ -268,6 +268,17 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
             dist.all_gather_into_tensor(g_sc, d_sc[b], group=env.nccl_group)
             dist.all_gather_into_tensor(g_cnt, d_cnt[b], group=env.nccl_group)
 
+    # setup, untimed like the index build before it: calls until the GPU's clocks have settled (up to 64 calls or 0.25 s) — behind a
+    # fresh build and the host work around it the first dozens of calls run ~10 % long, which `--steps 20 --warmup 5` would time
+    # (48.6 M q/s against 50.0 M with 60 warm-up steps or 200 timed ones, same box: profiles/r06last_settle_*).  Then the W
+    # warm-up steps and the K timed ones as asked for.
+    t_settle, n_settle = time.perf_counter(), 0
+    while n_settle < 64 and time.perf_counter() - t_settle < 0.25:
+        step(n_settle % n_b)
+        n_settle += 1
+        if n_settle % 8 == 0:
+            torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
     for i in range(warmup):
         step(i % n_b)
         gather(i % n_b)
@@ -582,6 +593,7 @@ def measure(env, args, w, steps, warmup, cpu_baseline=True, host_rate=True, traf
         "n_gpus": world,
         "steps": steps,
         "warmup": warmup,
+        "setup_settle_calls": n_settle,       # untimed calls of the setup, before the warm-up steps (clocks: see measure())
         "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": "%s synthetic strings (len 8-32 over [a-z0-9]%s), q=%d, %s>=%.2g, k=%d, %d-query batch per GPU, %d distinct batches in rotation"
                                % (_human(w["dict_size"]), "" if w["variant"] == "uniform" else ", variant " + w["variant"],
@@ -795,7 +807,7 @@ def main():
                "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u32 (posting/counter work) + f64 (final score)", "data": "synthetic",
                "config": rec["config"], "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"]}
-        for extra in ("host_buffers", "host_buffers_pipelined", "replicas_mode", "parity_vs_oracle"):
+        for extra in ("setup_settle_calls", "host_buffers", "host_buffers_pipelined", "replicas_mode", "parity_vs_oracle"):
             if extra in rec:
                 out[extra] = rec[extra]
         if sub_recs:
