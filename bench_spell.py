@@ -95,6 +95,14 @@ def run(args, env=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # (setup, untimed: calls until the clocks have settled — bench.py's measure() has the measurements behind it)
+    t_settle, n_settle = time.perf_counter(), 0
+    while n_settle < 64 and time.perf_counter() - t_settle < 0.25:
+        step(n_settle % n_b)
+        n_settle += 1
+        if n_settle % 8 == 0:
+            torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i % n_b)
     barrier()
@@ -196,7 +204,7 @@ def run(args, env=None):
                         "(sg_autocomplete_algorithmic_bytes, extrapolated from 8192 queries) over the same duration"}
         out = {
             "metric": "spellchecker predictions/sec (topK=%d, Cosine>=%.2g top-up) on a %dM-token LM, %dk-word vocabulary" % (top_k, sim, round(info["tokens"] / 1e6), len(lm) // 1000),
-            "value": world * n_q * args.steps / elapsed, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * n_q * args.steps / elapsed, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_settle_calls": n_settle,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (posting / counter / count-search work)", "data": "synthetic",
             "config": {"workload": "SpellChecker.Predict: %d-token synthetic corpus -> 3-gram LM (%d words, %d bigrams, %d trigrams) in the reference's .lm/.cdb formats; "
