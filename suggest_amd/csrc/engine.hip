@@ -1998,11 +1998,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
     if (!kParts) { my_slot = qi; my_part = pushed; }
     __syncthreads();
     const uint64_t pbase = (uint64_t)my_slot * SG_MAX_PARTS;
+    // (agent-scope stores here and loads in the merge below, on top of the release / acquire around the counter: the rows of a slot's
+    //  parts share cache lines — sixteen part_n words in one, short rows of several parts in another — that wavefronts on different
+    //  XCDs write side by side, and two fuzz reports this round look like one stale line of part_id read by the
+    //  merging part; these accesses go past the XCD's L2 whatever lines it holds)
     for (uint32_t i = lane; i < tk.n; i += 64) {
-      a.part_s[(pbase + my_part) * k + i] = tk.s[i];
-      a.part_id[(pbase + my_part) * k + i] = tk.id[i];
+      __hip_atomic_store(a.part_s + (pbase + my_part) * k + i, tk.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.part_id + (pbase + my_part) * k + i, tk.id[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) a.part_n[pbase + my_part] = tk.n;
+    if (lane == 0) __hip_atomic_store(a.part_n + pbase + my_part, tk.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (what this wavefront streamed of a sampled query: a split query's chunks are the sum over its parts, and only the part
     //  that merges reaches the accounting at the end)
     const bool sampled = !kLM && !a.autocomplete && a.fill_stat && (qi & a.fill_mask) == 0u;
@@ -2020,11 +2024,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kG8 ? 2 : 3,
     if (fin != n_parts) { if (sampled && lane == 0) atomicAdd((unsigned long long*)(a.fill_stat + 4), (unsigned long long)q_chunks); break; }   // somebody else finishes later and merges
     for (uint32_t pp = 0; pp < n_parts; pp++) {
       if (pp == my_part) continue;
-      const uint32_t np = __builtin_amdgcn_readfirstlane(a.part_n[pbase + pp]);
+      const uint32_t np = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.part_n + pbase + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       for (uint32_t i0 = 0; i0 < np; i0 += 64) {
         const uint32_t i = i0 + lane;
-        const uint64_t es = i < np ? a.part_s[(pbase + pp) * k + i] : 0ull;
-        const uint32_t ed = i < np ? a.part_id[(pbase + pp) * k + i] : 0u;
+        const uint64_t es = i < np ? __hip_atomic_load(a.part_s + (pbase + pp) * k + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const uint32_t ed = i < np ? __hip_atomic_load(a.part_id + (pbase + pp) * k + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const uint32_t cntl = min(64u, np - i0);
         for (uint32_t l = 0; l < cntl; l++) {
           const uint64_t sl = (uint64_t)readlane((uint32_t)es, (int)l) | ((uint64_t)readlane((uint32_t)(es >> 32), (int)l) << 32);
